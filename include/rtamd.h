@@ -232,7 +232,8 @@ typedef struct rtamd_render_stats {
  * and everything below it (ray.c, shading.c, lighting.c, texture.c:72-182).
  *   d_colour : DEVICE pointer, float[4*width*height], reference layout.
  *   d_hits   : DEVICE pointer or NULL; when given, rtamd_hit_record for the
- *              primary ray of every sample: index (width*j+i)*spp + k.
+ *              primary ray of every sample of the window, window-local index
+ *              ((j-y0)*(x1-x0) + (i-x0))*spp + k (whole frame: (width*j+i)*spp + k).
  *   stream   : hipStream_t (as void*), NULL = default stream.  The call is
  *              asynchronous unless `stats` is non-NULL (then it synchronises
  *              the stream to read counters back).

@@ -1,0 +1,665 @@
+// Device half of the C ABI (include/rtamd.h): context, scene flattening and
+// upload, and the host-side orchestration of the render pipeline.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "rtamd.h"
+#include "scene_dev.h"
+#include "kernels.h"
+#include "bvh_build.h"
+
+extern "C" void rtamd_set_error(const char *fmt, ...);
+
+#define TWO_PI 6.283185307179586476925287   /* cgmath.h:8 */
+
+#define HIP_TRY(expr)                                                              \
+	do {                                                                           \
+		hipError_t e_ = (expr);                                                    \
+		if (e_ != hipSuccess) {                                                    \
+			rtamd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+					__FILE__, __LINE__);                                           \
+			return RTAMD_ERR_HIP;                                                  \
+		}                                                                          \
+	} while (0)
+
+namespace {
+
+int g_device = -1;
+
+const unsigned QUEUE_CAPACITY_MAX = 1u << 26;   // rays per bounce queue (80 B each)
+const unsigned QUEUE_CAPACITY_MIN = 1u << 16;
+
+} // namespace
+
+struct rtamd_scene {
+	DevScene dev;
+	std::vector<void *> allocations;
+	rtamd_blob_header header;
+	bool fixed_consumption;      // no area light, no glossy+reflective material in use
+	bool glossy;                 // some material in use spawns reflection_samples children
+	// image-plane extents for the two `near` values the drivers pass
+	// lazily created work buffers
+	int32_t *d_glibc = nullptr;
+	uint32_t glibc_seed = 0;
+	unsigned long long glibc_n = 0;
+	long long *d_accum = nullptr;
+	unsigned long long accum_slots = 0;
+	QueueItem *d_queue[2] = { nullptr, nullptr };
+	unsigned queue_capacity = 0;
+	unsigned *d_qcount = nullptr;
+	DevCounters *d_counters = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int upload(rtamd_scene *sc, const std::vector<T> &host, const T **dev)
+{
+	*dev = nullptr;
+	size_t bytes = host.size() * sizeof(T);
+	void *p = nullptr;
+	HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+	sc->allocations.push_back(p);
+	if (bytes)
+		HIP_TRY(hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
+	*dev = static_cast<const T *>(p);
+	return 0;
+}
+
+void cross3(const double a[3], const double b[3], double c[3])   // vector.c:56-64
+{
+	c[0] = a[1] * b[2] - a[2] * b[1];
+	c[1] = a[2] * b[0] - a[0] * b[2];
+	c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+double dot3(const double a[3], const double b[3])                 // vector.c:31-34
+{
+	return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+bool float_valued(double v)
+{
+	return (double)(float)v == v;
+}
+
+} // namespace
+
+extern "C" int rtamd_init(int device)
+{
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		rtamd_set_error("rtamd_init: no HIP device available (%s)",
+				e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+		return RTAMD_ERR_HIP;
+	}
+	if (device < 0 || device >= count) {
+		rtamd_set_error("rtamd_init: device %d out of range (have %d)", device, count);
+		return RTAMD_ERR_ARG;
+	}
+	HIP_TRY(hipSetDevice(device));
+	g_device = device;
+	return 0;
+}
+
+extern "C" int rtamd_shutdown(void)
+{
+	g_device = -1;
+	return 0;
+}
+
+extern "C" const char *rtamd_version(void)
+{
+	return "rtamd 0.1 (gfx950)";
+}
+
+extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
+{
+	if (!sc)
+		return 0;
+	for (void *p : sc->allocations)
+		(void)hipFree(p);
+	if (sc->d_glibc) (void)hipFree(sc->d_glibc);
+	if (sc->d_accum) (void)hipFree(sc->d_accum);
+	if (sc->d_queue[0]) (void)hipFree(sc->d_queue[0]);
+	if (sc->d_queue[1]) (void)hipFree(sc->d_queue[1]);
+	if (sc->d_qcount) (void)hipFree(sc->d_qcount);
+	if (sc->d_counters) (void)hipFree(sc->d_counters);
+	delete sc;
+	return 0;
+}
+
+static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
+{
+	const rtamd_blob_header &h = sc->header;
+	DevScene &d = sc->dev;
+	std::memset(&d, 0, sizeof d);
+	d.width = h.width;
+	d.height = h.height;
+	d.antialiasing = h.antialiasing;
+	d.aa_samples = h.aa_samples;
+	d.shadow_samples = h.shadow_samples;
+	d.reflection_samples = h.reflection_samples;
+	d.max_reflections = h.max_reflections;
+	d.spp = h.antialiasing ? h.aa_samples * h.aa_samples : 1;
+	std::memcpy(d.cam_pos, h.cam_position, sizeof d.cam_pos);
+	std::memcpy(d.cam_u, h.cam_u, sizeof d.cam_u);
+	std::memcpy(d.cam_v, h.cam_v, sizeof d.cam_v);
+	std::memcpy(d.cam_w, h.cam_w, sizeof d.cam_w);
+	{
+		// ray.c:27-32; `near` is cam->near_plane with AA and the literal 1 without
+		// (raytracer.c:43,49)
+		double near = h.antialiasing ? (double)h.cam_near_plane : 1.0;
+		double width = 2 * near * tan(h.cam_fov * TWO_PI / 360. / 2.);
+		d.cam_width = width;
+		d.cam_left = -width / 2;
+		d.cam_height = width * h.height / (double)h.width;
+		d.cam_bottom = -d.cam_height / 2;
+		d.cam_d = (float)near;
+	}
+	d.background[0] = h.background[0];
+	d.background[1] = h.background[1];
+	d.background[2] = h.background[2];
+	d.num_lights = h.num_lights;
+	d.num_surfaces = h.num_surfaces;
+	d.has_cubemap = h.has_cubemap;
+
+	const rtamd_light *bl = reinterpret_cast<const rtamd_light *>(base + h.off_lights);
+	const rtamd_material *bm = reinterpret_cast<const rtamd_material *>(base + h.off_materials);
+	const rtamd_surface *bs = reinterpret_cast<const rtamd_surface *>(base + h.off_surfaces);
+	const rtamd_mesh *bmesh = reinterpret_cast<const rtamd_mesh *>(base + h.off_meshes);
+
+	std::vector<DevLight> lights(h.num_lights);
+	bool any_area = false;
+	for (int i = 0; i < h.num_lights; i++) {
+		DevLight &l = lights[i];
+		std::memset(&l, 0, sizeof l);
+		l.type = bl[i].type;
+		l.intensity = bl[i].intensity;
+		std::memcpy(l.position, bl[i].position, sizeof l.position);
+		std::memcpy(l.edge1, bl[i].edge1, sizeof l.edge1);
+		std::memcpy(l.edge2, bl[i].edge2, sizeof l.edge2);
+		l.colour[0] = bl[i].colour[0];
+		l.colour[1] = bl[i].colour[1];
+		l.colour[2] = bl[i].colour[2];
+		any_area |= l.type == RTAMD_LIGHT_AREA;
+	}
+	std::vector<DevMaterial> mats(h.num_materials);
+	for (int i = 0; i < h.num_materials; i++) {
+		DevMaterial &m = mats[i];
+		std::memset(&m, 0, sizeof m);
+		for (int c = 0; c < 3; c++) {
+			m.diffuse[c] = bm[i].diffuse[c];
+			m.specular[c] = bm[i].specular[c];
+		}
+		m.shininess = bm[i].shininess;
+		m.reflect = bm[i].reflect;
+		m.glossiness = bm[i].glossiness;
+	}
+
+	std::vector<DevSurface> surfs(h.num_surfaces);
+	bool any_reflective = false, any_glossy = false;
+	for (int i = 0; i < h.num_surfaces; i++) {
+		DevSurface &s = surfs[i];
+		std::memset(&s, 0, sizeof s);
+		std::memcpy(s.bbox, bs[i].bbox, sizeof s.bbox);
+		s.shape_type = bs[i].shape_type;
+		s.material = bs[i].material;
+		s.mesh = bs[i].mesh;
+		s.capped = bs[i].capped;
+		s.radius = bs[i].radius;
+		s.height = bs[i].height;
+		std::memcpy(s.w2m, bs[i].world_to_model, sizeof s.w2m);
+		s.affine = s.w2m[3] == 0.0 && s.w2m[7] == 0.0 && s.w2m[11] == 0.0 && s.w2m[15] == 1.0;
+		if (s.shape_type == RTAMD_SHAPE_PLANE) {
+			// ray.c:76-82: n = a x b, axn = a x n, bxn = b x n, det = a . bxn
+			cross3(bs[i].edge1, bs[i].edge2, s.pn);
+			cross3(bs[i].edge1, s.pn, s.paxn);
+			cross3(bs[i].edge2, s.pn, s.pbxn);
+			s.pdet = (float)dot3(bs[i].edge1, s.pbxn);
+		}
+		const rtamd_material &m = bm[s.material];
+		if (m.reflect > 0.0f) {
+			any_reflective = true;
+			if (m.glossiness > 0.0f)
+				any_glossy = true;
+		}
+	}
+	sc->fixed_consumption = !any_area && !any_glossy;
+	sc->glossy = any_glossy;
+	d.any_reflective = any_reflective && h.max_reflections >= 1;
+
+	// Meshes: leaf-ordered triangle and normal arrays, one BVH each.
+	std::vector<DevMesh> meshes(h.num_meshes);
+	std::vector<DevBvhNode> nodes;
+	std::vector<DevTriangle> tris, normals;
+	for (int m = 0; m < h.num_meshes; m++) {
+		const rtamd_mesh &bmh = bmesh[m];
+		const double *v = reinterpret_cast<const double *>(base + bmh.off_vertex);
+		const double *n = reinterpret_cast<const double *>(base + bmh.off_normal);
+		const int32_t *t = reinterpret_cast<const int32_t *>(base + bmh.off_triangle);
+		const int nt = bmh.num_triangles;
+		if (nt <= 0) {
+			rtamd_set_error("mesh %d has no triangles", m);
+			return RTAMD_ERR_ARG;
+		}
+		if (nt > (1 << 26)) {
+			rtamd_set_error("mesh %d has %d triangles; the limit is %d", m, nt, 1 << 26);
+			return RTAMD_ERR_LIMIT;
+		}
+		for (int i = 0; i < 3 * bmh.num_vertices; i++)
+			if (!float_valued(v[i])) {
+				rtamd_set_error("mesh %d: vertex coordinate %.17g is not a float value; mesh "
+						"coordinates must be float-representable (objreader narrows them, "
+						"mesh.c:93-95)", m, v[i]);
+				return RTAMD_ERR_ARG;
+			}
+		for (int i = 0; i < 3 * bmh.num_normals; i++)
+			if (!float_valued(n[i])) {
+				rtamd_set_error("mesh %d: normal component is not a float value", m);
+				return RTAMD_ERR_ARG;
+			}
+		std::vector<float> pos(9 * (size_t)nt);
+		for (int i = 0; i < nt; i++)
+			for (int c = 0; c < 3; c++)
+				for (int a = 0; a < 3; a++)
+					pos[9 * (size_t)i + 3 * c + a] = (float)v[3 * (size_t)t[6 * i + c] + a];
+		BvhResult bvh;
+		if (!bvh_build_mesh(pos.data(), nt, bvh)) {
+			rtamd_set_error("mesh %d: could not build a BVH within the traversal stack depth", m);
+			return RTAMD_ERR_LIMIT;
+		}
+		DevMesh &dm = meshes[m];
+		dm.node_first = (int32_t)nodes.size();
+		dm.tri_first = (int32_t)tris.size();
+		dm.root = bvh.root;
+		dm.num_triangles = nt;
+		nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+		for (int i = 0; i < nt; i++) {
+			int orig = bvh.order[i];
+			DevTriangle tp, tn;
+			std::memset(&tp, 0, sizeof tp);
+			std::memset(&tn, 0, sizeof tn);
+			for (int c = 0; c < 3; c++)
+				for (int a = 0; a < 3; a++) {
+					tp.v[4 * c + a] = pos[9 * (size_t)orig + 3 * c + a];
+					tn.v[4 * c + a] = (float)n[3 * (size_t)t[6 * orig + 3 + c] + a];
+				}
+			std::memcpy(&tp.v[3], &orig, 4);
+			tris.push_back(tp);
+			normals.push_back(tn);
+		}
+	}
+	if (nodes.empty())
+		nodes.emplace_back();
+
+	std::vector<float> texels;
+	if (h.has_cubemap) {
+		const rtamd_cubemap *bc = reinterpret_cast<const rtamd_cubemap *>(base + h.off_cubemap);
+		for (int f = 0; f < 6; f++) {
+			d.faces[f].width = bc->width[f];
+			d.faces[f].height = bc->height[f];
+			d.faces[f].offset = (int64_t)(texels.size() / 4);
+			const float *src = reinterpret_cast<const float *>(base + bc->off_face[f]);
+			texels.insert(texels.end(), src, src + 4 * (size_t)bc->width[f] * bc->height[f]);
+		}
+	}
+
+	int rc;
+	if ((rc = upload(sc, lights, &d.lights))) return rc;
+	if ((rc = upload(sc, mats, &d.materials))) return rc;
+	if ((rc = upload(sc, surfs, &d.surfaces))) return rc;
+	if ((rc = upload(sc, meshes, &d.meshes))) return rc;
+	if ((rc = upload(sc, nodes, &d.nodes))) return rc;
+	if ((rc = upload(sc, tris, &d.tris))) return rc;
+	if ((rc = upload(sc, normals, &d.normals))) return rc;
+	if ((rc = upload(sc, texels, &d.texels))) return rc;
+
+	void *p = nullptr;
+	HIP_TRY(hipMalloc(&p, sizeof(DevCounters)));
+	sc->d_counters = static_cast<DevCounters *>(p);
+	HIP_TRY(hipMalloc(&p, sizeof(unsigned) * 128));
+	sc->d_qcount = static_cast<unsigned *>(p);
+	return 0;
+}
+
+extern "C" int rtamd_scene_create(const void *blob, size_t blob_size, rtamd_scene **scene)
+{
+	if (!scene) {
+		rtamd_set_error("rtamd_scene_create: NULL output");
+		return RTAMD_ERR_ARG;
+	}
+	*scene = nullptr;
+	if (g_device < 0) {
+		rtamd_set_error("rtamd_scene_create: rtamd_init has not been called");
+		return RTAMD_ERR_ARG;
+	}
+	int rc = rtamd_blob_validate(blob, blob_size);
+	if (rc)
+		return rc;
+	rtamd_scene *sc = new rtamd_scene();
+	std::memcpy(&sc->header, blob, sizeof sc->header);
+	if (sc->header.max_reflections > 60) {
+		rtamd_set_error("max_reflections %d exceeds the limit of 60", sc->header.max_reflections);
+		delete sc;
+		return RTAMD_ERR_LIMIT;
+	}
+	rc = scene_create_impl(static_cast<const uint8_t *>(blob), sc);
+	if (rc) {
+		rtamd_scene_destroy(sc);
+		return rc;
+	}
+	*scene = sc;
+	return 0;
+}
+
+extern "C" int rtamd_scene_dims(const rtamd_scene *sc, int *width, int *height, int *spp)
+{
+	if (!sc) {
+		rtamd_set_error("rtamd_scene_dims: NULL scene");
+		return RTAMD_ERR_ARG;
+	}
+	if (width) *width = sc->dev.width;
+	if (height) *height = sc->dev.height;
+	if (spp) *spp = sc->dev.spp;
+	return 0;
+}
+
+// Fills in defaults and checks a parameter block against the frame.
+static int normalise_params(int width, int height, const rtamd_render_params *in, rtamd_render_params *p)
+{
+	if (!in) {
+		rtamd_set_error("render parameters are NULL");
+		return RTAMD_ERR_ARG;
+	}
+	*p = *in;
+	if (p->tile_w == 0) p->tile_w = 32;
+	if (p->tile_h == 0) p->tile_h = 32;
+	if (p->tile_stride == 0) p->tile_stride = 1;
+	if (p->tile_w < 1 || p->tile_h < 1 || p->tile_w > 4096 || p->tile_h > 4096 || p->tile_stride < 1 ||
+			p->tile_first < 0 || p->tile_first >= p->tile_stride) {
+		rtamd_set_error("bad tiling: tile %dx%d first %d stride %d", p->tile_w, p->tile_h, p->tile_first,
+				p->tile_stride);
+		return RTAMD_ERR_ARG;
+	}
+	bool whole = p->x0 == 0 && p->y0 == 0 && p->x1 == 0 && p->y1 == 0;
+	if (!whole && (p->x0 < 0 || p->y0 < 0 || p->x1 > width || p->y1 > height || p->x0 >= p->x1 || p->y0 >= p->y1)) {
+		rtamd_set_error("bad window [%d,%d)x[%d,%d) for a %dx%d frame", p->x0, p->x1, p->y0, p->y1, width, height);
+		return RTAMD_ERR_ARG;
+	}
+	if (p->rng_mode != RTAMD_RNG_GLIBC && p->rng_mode != RTAMD_RNG_KEYED) {
+		rtamd_set_error("unknown rng_mode %d", p->rng_mode);
+		return RTAMD_ERR_ARG;
+	}
+	return 0;
+}
+
+// The serial rand() stream for closed-form indexing (2 draws per primary sample).
+static int ensure_glibc_table(rtamd_scene *sc, uint32_t seed, hipStream_t stream)
+{
+	if (!sc->dev.antialiasing)
+		return 0;
+	unsigned long long n = 2ull * (unsigned long long)sc->dev.width * (unsigned long long)sc->dev.height *
+			(unsigned long long)sc->dev.spp;
+	if (n > (1ull << 31)) {
+		rtamd_set_error("the rand() stream table for this frame needs %llu entries; the limit is 2^31 "
+				"(use RTAMD_RNG_KEYED)", n);
+		return RTAMD_ERR_LIMIT;
+	}
+	if (sc->d_glibc && sc->glibc_seed == seed && sc->glibc_n == n)
+		return 0;
+	if (sc->d_glibc) {
+		HIP_TRY(hipStreamSynchronize(stream));
+		(void)hipFree(sc->d_glibc);
+		sc->d_glibc = nullptr;
+	}
+	std::vector<int32_t> table(n);
+	int rc = rtamd_glibc_rand_fill(seed, 0, n, table.data());
+	if (rc)
+		return rc;
+	void *p = nullptr;
+	HIP_TRY(hipMalloc(&p, n * sizeof(int32_t)));
+	sc->d_glibc = static_cast<int32_t *>(p);
+	HIP_TRY(hipMemcpy(p, table.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+	sc->glibc_seed = seed;
+	sc->glibc_n = n;
+	return 0;
+}
+
+extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, void *d_colour, void *d_hits,
+		rtamd_render_stats *stats, void *stream_v)
+{
+	if (!sc || !d_colour) {
+		rtamd_set_error("rtamd_render: NULL scene or output");
+		return RTAMD_ERR_ARG;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(stream_v);
+	rtamd_render_params p;
+	int rc = normalise_params(sc->dev.width, sc->dev.height, params, &p);
+	if (rc)
+		return rc;
+	if (p.rng_mode == RTAMD_RNG_GLIBC) {
+		if (!sc->fixed_consumption) {
+			rtamd_set_error("RTAMD_RNG_GLIBC needs a scene whose rand() consumption is fixed (no area "
+					"light, no glossy material); use RTAMD_RNG_KEYED");
+			return RTAMD_ERR_ARG;
+		}
+		if ((rc = ensure_glibc_table(sc, p.seed, stream)))
+			return rc;
+	}
+	if (d_hits && p.tile_stride != 1) {
+		rtamd_set_error("hit records are only available for single-owner renders (tile_stride 1)");
+		return RTAMD_ERR_ARG;
+	}
+	const DevScene &dev = sc->dev;
+	const unsigned long long pixels = rt_owned_pixels(dev.width, dev.height, p);
+	const unsigned long long samples = pixels * (unsigned)dev.spp;
+	if (pixels > 0xffffffffull) {
+		rtamd_set_error("too many pixels per call");
+		return RTAMD_ERR_LIMIT;
+	}
+	// work buffers
+	if (sc->accum_slots < pixels) {
+		if (sc->d_accum) {
+			HIP_TRY(hipStreamSynchronize(stream));
+			(void)hipFree(sc->d_accum);
+			sc->d_accum = nullptr;
+			sc->accum_slots = 0;
+		}
+		void *ptr = nullptr;
+		HIP_TRY(hipMalloc(&ptr, pixels * 3 * sizeof(long long) + 16));
+		sc->d_accum = static_cast<long long *>(ptr);
+		sc->accum_slots = pixels;
+	}
+	// worst-case children per primary sample at any level (shading.c:88: only
+	// depths 0 and 1 fan out)
+	unsigned long long fan = 1;
+	if (dev.any_reflective && sc->glossy) {
+		unsigned long long rs = (unsigned)(dev.reflection_samples > 1 ? dev.reflection_samples : 1);
+		fan = dev.max_reflections >= 2 ? rs * rs : rs;
+	}
+	unsigned long long chunk = samples;
+	if (dev.any_reflective) {
+		unsigned long long want = samples * fan;
+		unsigned cap = want > QUEUE_CAPACITY_MAX ? QUEUE_CAPACITY_MAX
+				: (want < QUEUE_CAPACITY_MIN ? QUEUE_CAPACITY_MIN : (unsigned)want);
+		if (sc->queue_capacity < cap) {
+			HIP_TRY(hipStreamSynchronize(stream));
+			for (int q = 0; q < 2; q++) {
+				if (sc->d_queue[q])
+					(void)hipFree(sc->d_queue[q]);
+				sc->d_queue[q] = nullptr;
+			}
+			sc->queue_capacity = 0;
+			for (int q = 0; q < 2; q++) {
+				void *ptr = nullptr;
+				HIP_TRY(hipMalloc(&ptr, (size_t)cap * sizeof(QueueItem)));
+				sc->d_queue[q] = static_cast<QueueItem *>(ptr);
+			}
+			sc->queue_capacity = cap;
+		}
+		chunk = sc->queue_capacity / fan;
+		chunk -= chunk % RT_BLOCK;
+		if (chunk < RT_BLOCK) {
+			rtamd_set_error("reflection_samples %d needs a larger ray queue than %u entries",
+					dev.reflection_samples, sc->queue_capacity);
+			return RTAMD_ERR_LIMIT;
+		}
+	}
+
+	hipEvent_t ev[2] = { nullptr, nullptr };
+	std::vector<hipEvent_t> pev;
+	if (stats) {
+		HIP_TRY(hipEventCreate(&ev[0]));
+		HIP_TRY(hipEventCreate(&ev[1]));
+		HIP_TRY(hipEventRecord(ev[0], stream));
+	}
+	HIP_TRY(hipMemsetAsync(sc->d_accum, 0, pixels * 3 * sizeof(long long), stream));
+	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DevCounters), stream));
+
+	int launches_primary = 0, launches_bounce = 0;
+	const int levels = dev.any_reflective ? dev.max_reflections : 0;
+	unsigned bounce_grid = 0;
+	if (levels) {
+		unsigned long long blocks = ((unsigned long long)sc->queue_capacity + RT_BLOCK - 1) / RT_BLOCK;
+		bounce_grid = blocks > 2048 ? 2048u : (unsigned)blocks;
+	}
+	for (unsigned long long first = 0; first < samples; first += chunk) {
+		unsigned long long count = samples - first < chunk ? samples - first : chunk;
+		if (levels)
+			HIP_TRY(hipMemsetAsync(sc->d_qcount, 0, sizeof(unsigned) * 128, stream));
+		if (stats && pev.size() < 4096) {
+			hipEvent_t a, b;
+			HIP_TRY(hipEventCreate(&a));
+			HIP_TRY(hipEventCreate(&b));
+			pev.push_back(a);
+			pev.push_back(b);
+			HIP_TRY(hipEventRecord(a, stream));
+		}
+		HIP_TRY(rt_launch_primary(dev, p, first, count, sc->d_glibc, sc->d_accum,
+				static_cast<rtamd_hit_record *>(d_hits), levels ? sc->d_queue[0] : nullptr,
+				levels ? sc->d_qcount : nullptr, sc->queue_capacity, sc->d_counters, stream));
+		if (stats && pev.size() <= 4096 && !pev.empty())
+			HIP_TRY(hipEventRecord(pev.back(), stream));
+		launches_primary++;
+		for (int level = 1; level <= levels; level++) {
+			// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
+			HIP_TRY(rt_launch_bounce(dev, sc->d_queue[(level - 1) & 1], sc->d_qcount + (level - 1),
+					sc->queue_capacity, sc->d_accum, level < levels ? sc->d_queue[level & 1] : nullptr,
+					sc->d_qcount + level, sc->d_counters, bounce_grid, stream));
+			launches_bounce++;
+		}
+	}
+	HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), stream));
+
+	if (stats) {
+		std::memset(stats, 0, sizeof *stats);
+		HIP_TRY(hipEventRecord(ev[1], stream));
+		HIP_TRY(hipEventSynchronize(ev[1]));
+		HIP_TRY(hipEventElapsedTime(&stats->ms_total, ev[0], ev[1]));
+		float sum = 0.0f;
+		for (size_t i = 0; i + 1 < pev.size(); i += 2) {
+			float ms = 0.0f;
+			HIP_TRY(hipEventElapsedTime(&ms, pev[i], pev[i + 1]));
+			sum += ms;
+		}
+		stats->ms_primary = sum;
+		for (hipEvent_t e : pev)
+			(void)hipEventDestroy(e);
+		(void)hipEventDestroy(ev[0]);
+		(void)hipEventDestroy(ev[1]);
+		DevCounters c;
+		HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+		stats->rays_primary = c.rays_primary;
+		stats->rays_shadow = c.rays_shadow;
+		stats->rays_secondary = c.rays_secondary;
+		stats->env_lookups = c.env_lookups;
+		stats->queue_peak = c.queue_peak;
+		stats->samples = samples;
+		stats->launches_primary = launches_primary;
+		stats->launches_bounce = launches_bounce;
+		if (c.queue_overflow) {
+			rtamd_set_error("a ray queue overflowed (%llu rays dropped)", c.queue_overflow);
+			return RTAMD_ERR_QUEUE;
+		}
+	}
+	return 0;
+}
+
+extern "C" int rtamd_trace(rtamd_scene *sc, const void *d_rays, uint64_t n, void *d_hits, void *stream_v)
+{
+	if (!sc || (n && (!d_rays || !d_hits))) {
+		rtamd_set_error("rtamd_trace: NULL argument");
+		return RTAMD_ERR_ARG;
+	}
+	if (n > (1ull << 31) * RT_BLOCK) {
+		rtamd_set_error("rtamd_trace: too many rays in one call");
+		return RTAMD_ERR_LIMIT;
+	}
+	HIP_TRY(rt_launch_trace(sc->dev, static_cast<const double *>(d_rays), n,
+			static_cast<rtamd_hit_record *>(d_hits), static_cast<hipStream_t>(stream_v)));
+	return 0;
+}
+
+extern "C" int rtamd_camera_rays(rtamd_scene *sc, const rtamd_render_params *params, void *d_rays, void *stream_v)
+{
+	if (!sc || !d_rays) {
+		rtamd_set_error("rtamd_camera_rays: NULL argument");
+		return RTAMD_ERR_ARG;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(stream_v);
+	rtamd_render_params p;
+	int rc = normalise_params(sc->dev.width, sc->dev.height, params, &p);
+	if (rc)
+		return rc;
+	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
+		return rc;
+	HIP_TRY(rt_launch_camera_rays(sc->dev, p, sc->d_glibc, static_cast<double *>(d_rays), stream));
+	return 0;
+}
+
+extern "C" int rtamd_tiles_owned(int width, int height, const rtamd_render_params *params)
+{
+	rtamd_render_params p;
+	int rc = normalise_params(width, height, params, &p);
+	if (rc)
+		return rc;
+	return rt_tiles_owned(width, height, p);
+}
+
+extern "C" int rtamd_tiles_pack(int width, int height, const rtamd_render_params *params, const void *d_frame,
+		void *d_packed, void *stream_v)
+{
+	rtamd_render_params p;
+	int rc = normalise_params(width, height, params, &p);
+	if (rc)
+		return rc;
+	if (!d_frame || !d_packed) {
+		rtamd_set_error("rtamd_tiles_pack: NULL buffer");
+		return RTAMD_ERR_ARG;
+	}
+	HIP_TRY(rt_launch_tiles_copy(width, height, p, static_cast<float *>(const_cast<void *>(d_frame)),
+			static_cast<float *>(d_packed), 0, static_cast<hipStream_t>(stream_v)));
+	return 0;
+}
+
+extern "C" int rtamd_tiles_unpack(int width, int height, const rtamd_render_params *params, const void *d_packed,
+		void *d_frame, void *stream_v)
+{
+	rtamd_render_params p;
+	int rc = normalise_params(width, height, params, &p);
+	if (rc)
+		return rc;
+	if (!d_frame || !d_packed) {
+		rtamd_set_error("rtamd_tiles_unpack: NULL buffer");
+		return RTAMD_ERR_ARG;
+	}
+	HIP_TRY(rt_launch_tiles_copy(width, height, p, static_cast<float *>(d_frame),
+			static_cast<float *>(const_cast<void *>(d_packed)), 1, static_cast<hipStream_t>(stream_v)));
+	return 0;
+}

@@ -1,0 +1,27 @@
+/* Host-callable launchers of the HIP kernels (kernels.hip). Internal. */
+#ifndef RTAMD_KERNELS_H
+#define RTAMD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "scene_dev.h"
+
+int rt_tiles_owned(int width, int height, const rtamd_render_params &p);
+unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_params &p);
+
+hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
+		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
+		long long *accum, rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count,
+		unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
+hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
+		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
+		DevCounters *counters, unsigned grid_blocks, hipStream_t stream);
+hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
+		unsigned long long pixel_count, const long long *accum, float *colour, hipStream_t stream);
+hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
+		rtamd_hit_record *hits, hipStream_t stream);
+hipError_t rt_launch_camera_rays(const DevScene &sc, const rtamd_render_params &p,
+		const int32_t *glibc_table, double *rays, hipStream_t stream);
+hipError_t rt_launch_tiles_copy(int width, int height, const rtamd_render_params &p, float *frame,
+		float *packed, int unpack, hipStream_t stream);
+
+#endif

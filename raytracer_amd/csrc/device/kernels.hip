@@ -1,0 +1,1259 @@
+// HIP kernels of the render path for gfx950 (wave64).
+//
+// Arithmetic contract: every quantity that decides WHICH surface or triangle a
+// ray hits, and the hit distance itself, is computed with the reference's own
+// mixture of double vectors and float scalars, one IEEE rounding per
+// operation (this file is compiled with -ffp-contract=off; the only fused
+// operations are the explicitly written __builtin_fmaf calls in the BVH box
+// test, which is this implementation's own conservative structure and never
+// produces a reported value).  Reference lines are cited per function.
+//
+// Execution model: one lane per primary sample.  A wave holds 64 consecutive
+// samples, i.e. for 64 samples per pixel all lanes of a wave share a pixel and
+// its rays are coherent in the BVH.  Shadow rays are traced in the lane that
+// owns the hit (they never leave registers); reflection / glossy rays go to a
+// bounce queue in HBM: lanes that spawn rays are compacted with a wave-wide
+// ballot + prefix count and the wave reserves its slots with one atomic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scene_dev.h"
+#include "kernels.h"
+
+namespace {
+
+struct d3 { double x, y, z; };
+struct c3 { float r, g, b; };
+
+#define DEV __device__ __forceinline__
+
+// ---- vector.c ---------------------------------------------------------------
+DEV d3 vadd(d3 a, d3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }          // vector.c:11
+DEV d3 vsub(d3 a, d3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }          // vector.c:21
+DEV double vdot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }        // vector.c:31
+DEV double vlen(d3 a) { return __builtin_sqrt(vdot(a, a)); }                     // vector.c:36
+DEV d3 vscale(double s, d3 a) { return { a.x * s, a.y * s, a.z * s }; }          // vector.c:41
+DEV d3 vnorm(d3 a) { return vscale(1 / vlen(a), a); }                            // vector.c:51
+DEV d3 vcross(d3 a, d3 b)                                                        // vector.c:56
+{
+	return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+DEV d3 ld3(const double *p) { return { p[0], p[1], p[2] }; }
+
+// ---- colour.c ---------------------------------------------------------------
+DEV c3 cadd(c3 a, c3 b) { return { a.r + b.r, a.g + b.g, a.b + b.b }; }          // colour.c:8
+DEV c3 cmul(c3 a, c3 b) { return { a.r * b.r, a.g * b.g, a.b * b.b }; }          // colour.c:19
+DEV c3 cscale(float s, c3 a) { return { s * a.r, s * a.g, s * a.b }; }           // colour.c:30
+DEV c3 lc3(const float *p) { return { p[0], p[1], p[2] }; }
+
+#define M4(m, i, j) (m)[4 * (j) + (i)]
+
+// matrix.c:61-81 + vector.c:95-104.  For an affine matrix the homogeneous
+// coordinate is exactly 1 and x / 1 == x, so the divide is skipped.
+DEV d3 xform_point(const DevSurface &s, d3 v)
+{
+	const double *m = s.w2m;
+	const double v0 = v.x, v1 = v.y, v2 = v.z, v3 = 1.0;
+	double x = M4(m, 0, 0) * v0 + M4(m, 0, 1) * v1 + M4(m, 0, 2) * v2 + M4(m, 0, 3) * v3;
+	double y = M4(m, 1, 0) * v0 + M4(m, 1, 1) * v1 + M4(m, 1, 2) * v2 + M4(m, 1, 3) * v3;
+	double z = M4(m, 2, 0) * v0 + M4(m, 2, 1) * v1 + M4(m, 2, 2) * v2 + M4(m, 2, 3) * v3;
+	if (s.affine)
+		return { x, y, z };
+	double w = M4(m, 3, 0) * v0 + M4(m, 3, 1) * v1 + M4(m, 3, 2) * v2 + M4(m, 3, 3) * v3;
+	return { x / w, y / w, z / w };
+}
+
+// matrix.c:83-96
+DEV d3 xform_dir(const double *m, d3 v)
+{
+	const double v0 = v.x, v1 = v.y, v2 = v.z;
+	d3 out;
+	out.x = M4(m, 0, 0) * v0 + M4(m, 0, 1) * v1 + M4(m, 0, 2) * v2 + M4(m, 0, 3) * 0;
+	out.y = M4(m, 1, 0) * v0 + M4(m, 1, 1) * v1 + M4(m, 1, 2) * v2 + M4(m, 1, 3) * 0;
+	out.z = M4(m, 2, 0) * v0 + M4(m, 2, 1) * v1 + M4(m, 2, 2) * v2 + M4(m, 2, 3) * 0;
+	return out;
+}
+
+// transpose(world_to_model) applied as a direction, ray.c:492-493,576
+DEV d3 xform_normal(const double *w, d3 n)
+{
+	const double n0 = n.x, n1 = n.y, n2 = n.z;
+	d3 out;
+	out.x = M4(w, 0, 0) * n0 + M4(w, 1, 0) * n1 + M4(w, 2, 0) * n2 + M4(w, 3, 0) * 0;
+	out.y = M4(w, 0, 1) * n0 + M4(w, 1, 1) * n1 + M4(w, 2, 1) * n2 + M4(w, 3, 1) * 0;
+	out.z = M4(w, 0, 2) * n0 + M4(w, 1, 2) * n1 + M4(w, 2, 2) * n2 + M4(w, 3, 2) * 0;
+	return out;
+}
+
+struct Ray {
+	d3 o, d;
+	float tnear, tfar;
+};
+
+// Candidate bookkeeping: the normal is only needed for the winning surface, so
+// each intersector reports how to rebuild it instead of the vector itself.
+enum NormalCode : int { NC_FROM_T = 0, NC_POS_Z = 1, NC_NEG_Z = 2, NC_PLANE_POS = 3, NC_PLANE_NEG = 4,
+	NC_MESH = 5, NC_SPHERE_UNIT = 6 };
+
+struct Best {
+	int surface;      // -1: none
+	int tri;          // leaf-order triangle index within the mesh (meshes only)
+	int ncode;
+	float t;          // Hit.t is a float-valued double (ray.c:485,574)
+	float a, b, c;    // barycentrics (meshes only)
+};
+
+// ---- keyed RNG (same definition as the CPU checker) ---------------------------
+DEV uint32_t mix32(uint32_t h)
+{
+	h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+	return h;
+}
+DEV uint32_t hash2(uint32_t a, uint32_t b)
+{
+	return mix32(a ^ (mix32(b) + 0x9e3779b9u + (a << 6) + (a >> 2)));
+}
+DEV uint32_t key0_of(uint32_t seed, uint32_t pixel, uint32_t sample) { return hash2(hash2(seed, pixel), sample); }
+DEV uint32_t key_child(uint32_t key, uint32_t child) { return hash2(key ^ 0xa511e9b3u, child + 1u); }
+// drand() = rand() / (double) RAND_MAX, ray.c:14-17
+DEV double keyed_drand(uint32_t key, uint32_t purpose, uint32_t index)
+{
+	return (double)(hash2(hash2(key, purpose), index) >> 1) / ((double)2147483647);
+}
+enum { PURPOSE_AA = 0, PURPOSE_LIGHT0 = 1, PURPOSE_GLOSSY = 16 };
+
+// ---- ray.c:580-641 ------------------------------------------------------------
+DEV bool surface_bbox_test(const float *bbox, const Ray &ray, float &bnear, float &bfar)
+{
+	float xmin = bbox[0], xmax = bbox[3];
+	float ymin = bbox[1], ymax = bbox[4];
+	float zmin = bbox[2], zmax = bbox[5];
+	float txmin, txmax, tymin, tymax, tzmin, tzmax;
+	float xd = (float)ray.d.x, yd = (float)ray.d.y, zd = (float)ray.d.z;
+	float xe = (float)ray.o.x, ye = (float)ray.o.y, ze = (float)ray.o.z;
+	float xa, ya, za;
+
+	xa = (float)(1.0 / (double)xd);
+	if (xa >= 0) { txmin = (xmin - xe) * xa; txmax = (xmax - xe) * xa; }
+	else         { txmin = (xmax - xe) * xa; txmax = (xmin - xe) * xa; }
+	ya = (float)(1.0 / (double)yd);
+	if (ya >= 0) { tymin = (ymin - ye) * ya; tymax = (ymax - ye) * ya; }
+	else         { tymin = (ymax - ye) * ya; tymax = (ymin - ye) * ya; }
+	za = (float)(1.0 / (double)zd);
+	if (za >= 0) { tzmin = (zmin - ze) * za; tzmax = (zmax - ze) * za; }
+	else         { tzmin = (zmax - ze) * za; tzmax = (zmin - ze) * za; }
+
+	if ((txmin > tymax) || (tymin > txmax)) return false;
+	if ((tymin > tzmax) || (tzmin > tymax)) return false;
+	if ((tzmin > txmax) || (txmin > tzmax)) return false;
+
+	// MAX/MIN macros of cgmath.h:15-16, written out so NaNs propagate the same way
+	float m0 = tzmin > ray.tnear ? tzmin : ray.tnear;
+	float m1 = tymin > m0 ? tymin : m0;
+	bnear = txmin > m1 ? txmin : m1;
+	float n0 = tzmax < ray.tfar ? tzmax : ray.tfar;
+	float n1 = tymax < n0 ? tymax : n0;
+	bfar = txmax < n1 ? txmax : n1;
+	return true;
+}
+
+// ---- primitives, model space --------------------------------------------------
+// Each returns the number of candidates (ray.c:500-524) and fills ts/ncodes.
+
+// ray.c:69-97
+DEV int plane_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+{
+	d3 n = ld3(s.pn), axn = ld3(s.paxn), bxn = ld3(s.pbxn);
+	double ddn = vdot(d, n);
+	float test_t = (float)(-vdot(o, n) / ddn);
+	d3 pos = vadd(o, vscale((double)test_t, d));
+	float det = s.pdet;
+	float alpha = (float)(vdot(pos, bxn) / (double)det);
+	float beta = (float)(-vdot(pos, axn) / (double)det);
+	if (alpha < 0 || alpha > 1 || beta < 0 || beta > 1)
+		return 0;
+	ts[0] = test_t;
+	nc[0] = ddn < 0 ? NC_PLANE_POS : NC_PLANE_NEG;
+	return 1;
+}
+
+// ray.c:99-120
+DEV int disk_intersect(const DevSurface &s, d3 o, d3 d, float tnear, float ts[2], int nc[2])
+{
+	if (d.z == 0)
+		return 0;
+	double tt = -o.z / d.z;
+	double xx = o.x + tt * d.x;
+	double yy = o.y + tt * d.y;
+	float r2 = s.radius * s.radius;
+	if (xx * xx + yy * yy > (double)r2)
+		return 0;
+	ts[0] = (float)tt;
+	nc[0] = (o.z + (double)tnear * d.z >= 0) ? NC_POS_Z : NC_NEG_Z;
+	return 1;
+}
+
+// ray.c:122-151
+DEV int sphere_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+{
+	float radius = s.radius;
+	float vv = (float)vdot(o, o);
+	float vd = (float)vdot(o, d);
+	float dd = (float)vdot(d, d);
+	float disc = vd * vd - dd * (vv - radius * radius);
+	if (disc < 0)
+		return 0;
+	else if (disc == 0) {
+		ts[0] = -vd / dd;
+		nc[0] = NC_SPHERE_UNIT;
+		return 1;
+	}
+	float sq = __builtin_sqrtf(disc);
+	ts[0] = (-vd - sq) / dd;
+	ts[1] = (-vd + sq) / dd;
+	nc[0] = nc[1] = NC_FROM_T;
+	return 2;
+}
+
+// ray.c:153-271
+DEV int cylinder_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+{
+	const float height = s.height, radius = s.radius;
+	const bool capped = s.capped != 0;
+	float a = (float)(d.x * d.x + d.y * d.y);
+	float b = (float)(2 * (o.x * d.x + o.y * d.y));
+	float c = (float)(o.x * o.x + o.y * o.y - (double)(radius * radius));
+	float disc = b * b - 4 * a * c;
+	if (disc < 0)
+		return 0;
+	float sq = __builtin_sqrtf(disc);
+	ts[0] = (-b - sq) / (2 * a);
+	ts[1] = (-b + sq) / (2 * a);
+	nc[0] = nc[1] = NC_FROM_T;
+	float z0 = (float)(o.z + (double)ts[0] * d.z);
+	float z1 = (float)(o.z + (double)ts[1] * d.z);
+	if ((z0 < 0 && z1 < 0) || (z0 > height && z1 > height))
+		return 0;
+	float tbot = (float)(-o.z / d.z);
+	float ttop = (float)(((double)height - o.z) / d.z);
+	if ((z0 < 0 && z1 > height) || (z0 > height && z1 < 0)) {
+		if (!capped)
+			return 0;
+		ts[0] = tbot; nc[0] = NC_NEG_Z;
+		ts[1] = ttop; nc[1] = NC_POS_Z;
+	} else if (z0 >= 0 && z0 <= height && z1 > height) {
+		if (capped) { ts[1] = ttop; nc[1] = NC_POS_Z; }
+		else        { ts[1] = ts[0]; }
+	} else if (z0 >= 0 && z0 <= height && z1 < 0) {
+		if (capped) { ts[1] = tbot; nc[1] = NC_NEG_Z; }
+		else        { ts[1] = ts[0]; }
+	} else if (z1 >= 0 && z1 <= height && z0 > height) {
+		if (capped) { ts[0] = ttop; nc[0] = NC_POS_Z; }
+		else        { ts[0] = ts[1]; }
+	} else if (z1 >= 0 && z1 <= height && z0 < 0) {
+		if (capped) { ts[0] = tbot; nc[0] = NC_NEG_Z; }
+		else        { ts[0] = ts[1]; }
+	} else if (z0 >= 0 && z0 <= height && z1 >= 0 && z1 <= height) {
+		// nothing to fix
+	} else {
+		return 0;   // the reference traps here (ray.c:263-268); reported as a miss
+	}
+	return 2;
+}
+
+// ray.c:273-324 (reports ONE candidate, ray.c:323)
+DEV int cone_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+{
+	float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+	float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+	float R = s.radius, h = s.height;
+	float k = R / h;
+	float a = dx * dx + dy * dy - (k * dz) * (k * dz);
+	float b = 2 * (ox * dx + oy * dy + (k * k) * (-oz * dz + h * dz));
+	float c = ox * ox + oy * oy - (k * k) * (h * h - 2 * h * oz + oz * oz);
+	float disc = b * b - 4 * a * c;
+	if (disc < 0)
+		return 0;
+	float sq = __builtin_sqrtf(disc);
+	float t0 = (-b - sq) / (2 * a);
+	float t1 = (-b + sq) / (2 * a);
+	float z0 = oz + t0 * dz;
+	float z1 = oz + t1 * dz;
+	if ((z0 > h || z0 < 0) && (z1 > h || z1 < 0))
+		return 0;
+	else if (z0 > h || z0 < 0)
+		t0 = t1;
+	ts[0] = t0;
+	nc[0] = NC_FROM_T;
+	return 1;
+}
+
+// Model-space normal of an analytic primitive for the winning candidate.
+DEV d3 primitive_normal(const DevSurface &s, d3 o, d3 d, float t, int ncode)
+{
+	switch (ncode) {
+	case NC_POS_Z: return { 0, 0, 1 };
+	case NC_NEG_Z: return { 0, 0, -1 };
+	case NC_PLANE_POS: return ld3(s.pn);
+	case NC_PLANE_NEG: return vscale(-1, ld3(s.pn));
+	default: break;
+	}
+	switch (s.shape_type) {
+	case RTAMD_SHAPE_SPHERE: {
+		d3 p = vadd(o, vscale((double)t, d));                 // ray.c:139-148
+		return ncode == NC_SPHERE_UNIT ? vnorm(p) : p;
+	}
+	case RTAMD_SHAPE_CYLINDER: {                               // ray.c:174-180
+		double r = (double)s.radius;
+		return { (o.x + (double)t * d.x) / r, (o.y + (double)t * d.y) / r, 0 };
+	}
+	case RTAMD_SHAPE_CONE: {                                   // ray.c:311-315
+		float dx = (float)d.x, dy = (float)d.y;
+		float ox = (float)o.x, oy = (float)o.y;
+		float R = s.radius, h = s.height;
+		float sl = __builtin_sqrtf(h * h + R * R);
+		float px = ox + t * dx, py = oy + t * dy;
+		float rho = __builtin_sqrtf(px * px + py * py);
+		float nx = h / sl * px / rho;
+		float ny = h / sl * py / rho;
+		float nz = R / sl;
+		return { (double)nx, (double)ny, (double)nz };
+	}
+	default:
+		return { 0, 0, 0 };
+	}
+}
+
+// ---- triangles ---------------------------------------------------------------
+
+// ray.c:327-358.  Vertices are float-valued (objreader narrows every coordinate
+// to float, mesh.c:93-95), so they are stored as floats and widened here.
+DEV bool triangle_intersect(d3 o, d3 d, const float4 &p0, const float4 &p1, const float4 &p2,
+		float &aa, float &bb, float &cc, double &t)
+{
+	d3 u = { (double)p0.x, (double)p0.y, (double)p0.z };
+	d3 v = { (double)p1.x, (double)p1.y, (double)p1.z };
+	d3 w = { (double)p2.x, (double)p2.y, (double)p2.z };
+	d3 edge1 = vsub(v, u);
+	d3 edge2 = vsub(w, u);
+	d3 pvec = vcross(d, edge2);
+	float det = (float)vdot(edge1, pvec);
+	d3 tvec = vsub(o, u);
+	bb = (float)(vdot(tvec, pvec) / (double)det);
+	if ((double)bb < 0.0 || (double)bb > 1.0)
+		return false;
+	d3 qvec = vcross(tvec, edge1);
+	cc = (float)(vdot(d, qvec) / (double)det);
+	if ((double)cc < 0.0 || (double)(cc + bb) > 1.0)
+		return false;
+	aa = (float)(1.0 - (double)bb - (double)cc);
+	t = vdot(edge2, qvec) / (double)det;
+	return true;
+}
+
+// Float ray used only for the BVH box tests.  The boxes are exact (float-valued
+// vertices); what is rounded is the ray, so each slab distance is pushed
+// outwards: the origin is moved by its own rounding error away from the box
+// side being tested, and the entry/exit distances get a relative margin that
+// covers the rounding of 1/d, the subtraction and the product.
+struct BoxRay {
+	float onx, ony, onz;      // origin used for entry planes
+	float ofx, ofy, ofz;      // origin used for exit planes
+	float ix, iy, iz;         // 1/d
+	bool sx, sy, sz;          // d < 0
+};
+
+DEV BoxRay make_box_ray(d3 o, d3 d)
+{
+	BoxRay r;
+	float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+	// a zero component would turn (plane - o) * inf into NaN on the plane itself
+	if (__builtin_fabsf(fx) < 1e-30f) fx = __builtin_copysignf(1e-30f, fx);
+	if (__builtin_fabsf(fy) < 1e-30f) fy = __builtin_copysignf(1e-30f, fy);
+	if (__builtin_fabsf(fz) < 1e-30f) fz = __builtin_copysignf(1e-30f, fz);
+	r.ix = 1.0f / fx; r.iy = 1.0f / fy; r.iz = 1.0f / fz;
+	r.sx = fx < 0; r.sy = fy < 0; r.sz = fz < 0;
+	float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+	const float ulp = 1.1920929e-7f;      // 2^-23 >= the rounding error of the narrowing
+	float px = __builtin_fabsf(ox) * ulp, py = __builtin_fabsf(oy) * ulp, pz = __builtin_fabsf(oz) * ulp;
+	// entry distance (plane - o) * i must not grow: move o towards +d, exit the other way
+	r.onx = r.sx ? ox - px : ox + px;  r.ofx = r.sx ? ox + px : ox - px;
+	r.ony = r.sy ? oy - py : oy + py;  r.ofy = r.sy ? oy + py : oy - py;
+	r.onz = r.sz ? oz - pz : oz + pz;  r.ofz = r.sz ? oz + pz : oz - pz;
+	return r;
+}
+
+// Conservative slab test; returns the (widened) entry distance in tn.
+DEV bool box_test(const BoxRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+		float tlo, float thi, float &tn)
+{
+	const float margin = 9.5367431640625e-7f;   // 2^-20
+	float nx = ((r.sx ? hix : lox) - r.onx) * r.ix;
+	float ny = ((r.sy ? hiy : loy) - r.ony) * r.iy;
+	float nz = ((r.sz ? hiz : loz) - r.onz) * r.iz;
+	float fx = ((r.sx ? lox : hix) - r.ofx) * r.ix;
+	float fy = ((r.sy ? loy : hiy) - r.ofy) * r.iy;
+	float fz = ((r.sz ? loz : hiz) - r.ofz) * r.iz;
+	float tnn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
+	float tff = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+	tnn = __builtin_fmaf(-__builtin_fabsf(tnn), margin, tnn);
+	tff = __builtin_fmaf(__builtin_fabsf(tff), margin, tff);
+	tn = __builtin_fmaxf(tnn, tlo);
+	float tf = __builtin_fminf(tff, thi);
+	return tn <= tf;
+}
+
+DEV float as_f(int v) { return __builtin_bit_cast(float, v); }
+DEV int as_i(float v) { return __builtin_bit_cast(int, v); }
+// smallest float strictly above a finite x
+DEV float next_up(float x)
+{
+	if (x == 0.0f)
+		return 1.401298464e-45f;
+	int i = as_i(x);
+	i += x > 0.0f ? 1 : -1;
+	return as_f(i);
+}
+
+// Nearest triangle of a mesh inside [tnear, tfar] (effective result of
+// ray.c:360-462: smallest t among triangles that pass the barycentric tests;
+// equal t -> the triangle with the highest index in the mesh's own array, which
+// is what the kd leaf loop's `<=` at ray.c:376 gives inside a leaf).
+// ANYHIT: stop at the first acceptable triangle (shadow rays only need to know
+// whether ray_intersect would return true, shading.c:48).
+template <bool ANYHIT>
+DEV bool mesh_traverse(const DevScene &sc, const DevMesh &mesh, d3 o, d3 d, float tnear, float tfar,
+		int *stack, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
+{
+	const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes + mesh.node_first);
+	const float4 *tris = reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first);
+	const BoxRay br = make_box_ray(o, d);
+	const double dnear = (double)tnear, dfar = (double)tfar;
+	bool found = false;
+	best_t = __builtin_huge_val();
+	best_orig = -1;
+	best_tri = -1;
+	float limit = tfar;          // float upper bound of the search window, >= best_t
+	int sp = 0;
+	int ref = mesh.root;
+	for (;;) {
+		if (ref >= 0) {
+			const float4 q0 = nodes[4 * ref + 0], q1 = nodes[4 * ref + 1];
+			const float4 q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
+			float tn0, tn1;
+			bool h0 = box_test(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0);
+			bool h1 = box_test(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1);
+			int c0 = as_i(q3.x), c1 = as_i(q3.y);
+			if (h0 && h1) {
+				bool swap = tn1 < tn0;
+				int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+				if (sp < RT_MAX_STACK) {
+					stack[sp * RT_BLOCK] = farc;
+					sp++;
+				}
+				ref = nearc;
+				continue;
+			} else if (h0) {
+				ref = c0;
+				continue;
+			} else if (h1) {
+				ref = c1;
+				continue;
+			}
+		} else {
+			int v = ~ref;
+			int first = v >> 2, count = (v & 3) + 1;
+			for (int i = 0; i < count; i++) {
+				const float4 p0 = tris[3 * (first + i) + 0];
+				const float4 p1 = tris[3 * (first + i) + 1];
+				const float4 p2 = tris[3 * (first + i) + 2];
+				float aa, bb, cc;
+				double t;
+				if (!triangle_intersect(o, d, p0, p1, p2, aa, bb, cc, t))
+					continue;
+				int orig = as_i(p0.w);
+				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
+					best_t = t;
+					best_orig = orig;
+					best_tri = first + i;
+					ba = aa; bb_ = bb; bc = cc;
+					found = true;
+					if (ANYHIT)
+						return true;
+					// next float above or equal to t: boxes further than this cannot win
+					float ft = (float)t;
+					if ((double)ft < t)
+						ft = next_up(ft);
+					limit = ft < tfar ? ft : tfar;
+				}
+			}
+		}
+		if (sp == 0)
+			break;
+		sp--;
+		ref = stack[sp * RT_BLOCK];
+	}
+	return found;
+}
+
+// ---- ray.c:483-578 + 643-672 ---------------------------------------------------
+
+template <bool ANYHIT>
+DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
+{
+	best.surface = -1;
+	best.tri = -1;
+	best.t = __builtin_huge_valf();
+	for (int si = 0; si < sc.num_surfaces; si++) {
+		const DevSurface &s = sc.surfaces[si];
+		float bnear, bfar;
+		if (!surface_bbox_test(s.bbox, ray, bnear, bfar))
+			continue;
+		d3 o = xform_point(s, ray.o);
+		d3 d = xform_dir(s.w2m, ray.d);
+		float ts[2] = { -__builtin_huge_valf(), -__builtin_huge_valf() };
+		int nc[2] = { NC_FROM_T, NC_FROM_T };
+		int hits;
+		int tri = -1;
+		float ba = 0, bb = 0, bc = 0;
+		switch (s.shape_type) {
+		case RTAMD_SHAPE_PLANE: hits = plane_intersect(s, o, d, ts, nc); break;
+		case RTAMD_SHAPE_DISK: hits = disk_intersect(s, o, d, bnear, ts, nc); break;
+		case RTAMD_SHAPE_SPHERE: hits = sphere_intersect(s, o, d, ts, nc); break;
+		case RTAMD_SHAPE_CYLINDER: hits = cylinder_intersect(s, o, d, ts, nc); break;
+		case RTAMD_SHAPE_CONE: hits = cone_intersect(s, o, d, ts, nc); break;
+		default: {
+			int orig;
+			double t;
+			hits = mesh_traverse<ANYHIT>(sc, sc.meshes[s.mesh], o, d, bnear, bfar, stack,
+					tri, orig, t, ba, bb, bc) ? 1 : 0;
+			ts[0] = (float)t;                       // ray.c:471
+			nc[0] = NC_MESH;
+			break;
+		}
+		}
+		if (hits == 0)
+			continue;
+		float t;
+		int ncode;
+		if (hits == 1) {                             // ray.c:530-536
+			if (ts[0] < bnear || ts[0] > bfar)
+				continue;
+			t = ts[0];
+			ncode = nc[0];
+		} else {                                     // ray.c:537-567
+			bool t0_ok = ts[0] >= bnear && ts[0] <= bfar;
+			bool t1_ok = ts[1] >= bnear && ts[1] <= bfar;
+			if (!t0_ok && !t1_ok)
+				continue;
+			else if (t0_ok && !t1_ok) { t = ts[0]; ncode = nc[0]; }
+			else if (!t0_ok && t1_ok) { t = ts[1]; ncode = nc[1]; }
+			else if (ts[0] < ts[1]) { t = ts[0]; ncode = nc[0]; }
+			else { t = ts[1]; ncode = nc[1]; }
+		}
+		if (ANYHIT) {
+			best.surface = si;
+			return true;
+		}
+		// ray.c:661: first hit or strictly smaller t
+		if (best.surface < 0 || (double)t < (double)best.t) {
+			best.surface = si;
+			best.t = t;
+			best.ncode = ncode;
+			best.tri = tri;
+			best.a = ba; best.b = bb; best.c = bc;
+		}
+	}
+	return best.surface >= 0;
+}
+
+// Position and world-space normal of the winning hit, ray.c:574-576.
+DEV void finish_hit(const DevScene &sc, const Ray &ray, const Best &best, d3 &position, d3 &normal)
+{
+	const DevSurface &s = sc.surfaces[best.surface];
+	position = vadd(ray.o, vscale((double)best.t, ray.d));
+	d3 n;
+	if (best.ncode == NC_MESH) {
+		// ray.c:472-475
+		const DevMesh &mesh = sc.meshes[s.mesh];
+		const float4 *nrm = reinterpret_cast<const float4 *>(sc.normals + mesh.tri_first) + 3 * best.tri;
+		const float4 a = nrm[0], b = nrm[1], c = nrm[2];
+		d3 n0 = { (double)a.x, (double)a.y, (double)a.z };
+		d3 n1 = { (double)b.x, (double)b.y, (double)b.z };
+		d3 n2 = { (double)c.x, (double)c.y, (double)c.z };
+		n = vadd(vadd(vscale((double)best.a, n0), vscale((double)best.b, n1)), vscale((double)best.c, n2));
+	} else {
+		d3 o = xform_point(s, ray.o);
+		d3 d = xform_dir(s.w2m, ray.d);
+		n = primitive_normal(s, o, d, best.t, best.ncode);
+	}
+	normal = vnorm(xform_normal(s.w2m, n));
+}
+
+// ---- texture.c:72-116, 135-182 -------------------------------------------------
+
+DEV c3 texel_at(const DevScene &sc, const DevCubeFace &f, int x, int y)
+{
+	const float4 v = reinterpret_cast<const float4 *>(sc.texels)[f.offset + (int64_t)f.width * y + x];
+	return { v.x, v.y, v.z };
+}
+
+DEV c3 texture_texel(const DevScene &sc, int face, double u, double v)
+{
+	const DevCubeFace f = sc.faces[face];
+	if (u == 1.0) u -= 1e-6;
+	if (v == 1.0) v -= 1e-6;
+	u = u - __builtin_floor(u);
+	v = v - __builtin_floor(v);
+	u *= f.width;
+	v *= f.height;
+	int x0 = (int)__builtin_floor(u);
+	int y0 = (int)__builtin_floor(v);
+	double ualpha = u - x0, valpha = v - y0;
+	double ubeta = 1 - ualpha, vbeta = 1 - valpha;
+	int x1 = (x0 == f.width - 1) ? x0 : x0 + 1;
+	int y1 = (y0 == f.height - 1) ? y0 : y0 + 1;
+	// out-of-range coordinates can only come from a NaN direction; keep the fetch in bounds
+	x0 = min(max(x0, 0), f.width - 1);  x1 = min(max(x1, 0), f.width - 1);
+	y0 = min(max(y0, 0), f.height - 1); y1 = min(max(y1, 0), f.height - 1);
+	c3 caa = texel_at(sc, f, x0, y0), cab = texel_at(sc, f, x1, y0);
+	c3 cba = texel_at(sc, f, x0, y1), cbb = texel_at(sc, f, x1, y1);
+	return cadd(cscale((float)vbeta, cadd(cscale((float)ubeta, caa), cscale((float)ualpha, cab))),
+			cscale((float)valpha, cadd(cscale((float)ubeta, cba), cscale((float)ualpha, cbb))));
+}
+
+DEV c3 cubemap_colour(const DevScene &sc, d3 d)
+{
+	int face = -1;
+	float u = 0.0f, v = 0.0f;
+	double dx = __builtin_fabs(d.x), dy = __builtin_fabs(d.y), dz = __builtin_fabs(d.z);
+	if (dx >= dy && dx >= dz) {
+		if (d.x >= 0) { u = (float)((1.0 + d.z / d.x) / 2.0); v = (float)((1.0 + d.y / d.x) / 2.0); face = 1; }
+		else { u = (float)(1.0 - (1.0 - d.z / d.x) / 2.0); v = (float)((1.0 - d.y / d.x) / 2.0); face = 0; }
+	} else if (dy >= dz && dy >= dx) {
+		if (d.y >= 0) { u = (float)((1.0 + d.x / d.y) / 2.0); v = (float)(1.0 - (1.0 - d.z / d.y) / 2.0); face = 3; }
+		else { u = (float)((1.0 - d.x / d.y) / 2.0); v = (float)((1.0 + d.z / d.y) / 2.0); face = 2; }
+	} else if (dz >= dx && dz >= dy) {
+		if (d.z >= 0) { u = (float)(1.0 - (1.0 + d.x / d.z) / 2.0); v = (float)((1.0 + d.y / d.z) / 2.0); face = 5; }
+		else { u = (float)((1.0 - d.x / d.z) / 2.0); v = (float)((1.0 - d.y / d.z) / 2.0); face = 4; }
+	}
+	if (face < 0)
+		return { 0.0f, 0.0f, 0.0f };
+	return texture_texel(sc, face, (double)u, (double)v);
+}
+
+// ---- lighting.c ----------------------------------------------------------------
+
+// lighting.c:7-19
+DEV c3 diff_colour(const DevLight &light, const DevMaterial &mat, d3 light_dir, d3 normal)
+{
+	double dp = vdot(light_dir, normal);
+	float ndotv = (float)(0 > dp ? 0.0 : dp);
+	c3 light_col = cscale(light.intensity, cscale(ndotv, lc3(light.colour)));
+	return cmul(lc3(mat.diffuse), light_col);
+}
+
+// lighting.c:21-34 (called with cam_dir and light_dir swapped, shading.c:52; the
+// half vector is symmetric in them)
+DEV c3 spec_colour(const DevLight &light, const DevMaterial &mat, d3 first, d3 second, d3 normal)
+{
+	d3 half = vnorm(vadd(first, second));
+	double dp = vdot(half, normal);
+	float base = (float)(0 > dp ? 0.0 : dp);
+	float hdotn = __builtin_powf(base, (float)mat.shininess);
+	c3 light_col = cscale(light.intensity, cscale(hdotn, lc3(light.colour)));
+	return cmul(lc3(mat.specular), light_col);
+}
+
+// ---- wave helpers ------------------------------------------------------------
+
+DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Adds per-lane counts into a global counter with one atomic per wave.
+DEV void wave_count_add(unsigned long long *counter, unsigned value)
+{
+	unsigned total = value;
+	for (int off = 32; off > 0; off >>= 1)
+		total += __shfl_xor(total, off, 64);
+	if (lane_id() == 0 && total)
+		atomicAdd(counter, (unsigned long long)total);
+}
+
+DEV long long to_fixed(float c)
+{
+	// NaN and infinities cannot be accumulated; the quantiser maps them to 0 / 255 anyway
+	if (!(c == c)) return 0;
+	double v = (double)c;
+	if (v > 1.0e6) v = 1.0e6;
+	if (v < -1.0e6) v = -1.0e6;
+	return __double2ll_rn(v * RT_FIX_SCALE);
+}
+
+DEV void accumulate(long long *accum, uint32_t slot, c3 c)
+{
+	unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
+	long long r = to_fixed(c.r), g = to_fixed(c.g), b = to_fixed(c.b);
+	if (r) atomicAdd(p + 0, (unsigned long long)r);
+	if (g) atomicAdd(p + 1, (unsigned long long)g);
+	if (b) atomicAdd(p + 2, (unsigned long long)b);
+}
+
+// ---- shading of one path vertex: shading.c:114-141 without the recursion ------
+//
+// Returns the radiance this vertex contributes directly (environment, or the sum
+// of the light loops) and pushes reflection / glossy children into the bounce
+// queue with their throughput weight.
+
+struct ShadeIO {
+	const DevScene *sc;
+	int rng_mode;
+	QueueItem *queue_out;
+	unsigned *queue_count;
+	unsigned queue_capacity;
+	DevCounters *counters;
+};
+
+DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t key, c3 weight,
+		uint32_t slot, bool active, int *stack, rtamd_hit_record *rec,
+		unsigned &n_shadow, unsigned &n_env)
+{
+	const DevScene &sc = *io.sc;
+	c3 total = { 0.0f, 0.0f, 0.0f };
+	Best best;
+	bool hit = false;
+	d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
+	if (active) {
+		hit = trace<false>(sc, ray, stack, best);
+		if (hit)
+			finish_hit(sc, ray, best, position, normal);
+	}
+	if (rec && active) {
+		rtamd_hit_record r;
+		r.surface = hit ? best.surface : -1;
+		r.triangle = -1;
+		if (hit && best.ncode == NC_MESH) {
+			const DevMesh &mesh = sc.meshes[sc.surfaces[best.surface].mesh];
+			r.triangle = as_i(reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first)[3 * best.tri].w);
+		}
+		r.t = hit ? best.t : 0.0f;
+		r.pad = 0.0f;
+		r.position[0] = position.x; r.position[1] = position.y; r.position[2] = position.z;
+		r.normal[0] = normal.x; r.normal[1] = normal.y; r.normal[2] = normal.z;
+		*rec = r;
+	}
+
+	int n_children = 0;
+	const DevMaterial *mat = nullptr;
+	if (active && !hit) {
+		// shading.c:123-129
+		if (sc.has_cubemap) {
+			total = cubemap_colour(sc, ray.d);
+			n_env++;
+		} else
+			total = lc3(sc.background);
+	} else if (active) {
+		mat = &sc.materials[sc.surfaces[best.surface].material];
+		d3 cam_dir = vnorm(vscale(-1, ray.d));                       // shading.c:118
+		// shading.c:133-135 -> hit_light_colour, shading.c:7-58
+		for (int li = 0; li < sc.num_lights; li++) {
+			const DevLight &light = sc.lights[li];
+			const bool area = light.type == RTAMD_LIGHT_AREA;
+			const int n = area ? sc.shadow_samples : 1;
+			c3 light_total = { 0.0f, 0.0f, 0.0f };
+			d3 lpos = ld3(light.position);
+			for (int j = 0; j < n * n; j++) {
+				d3 light_pos = lpos;
+				if (area) {
+					int p = j % n, q = j / n;
+					float alpha = (float)((double)((float)p / (float)n) +
+							keyed_drand(key, PURPOSE_LIGHT0 + (uint32_t)li, 2u * (uint32_t)j));
+					float beta = (float)((double)((float)q / (float)n) +
+							keyed_drand(key, PURPOSE_LIGHT0 + (uint32_t)li, 2u * (uint32_t)j + 1u));
+					light_pos = vadd(vadd(lpos, vscale((double)alpha, ld3(light.edge1))),
+							vscale((double)beta, ld3(light.edge2)));
+				}
+				d3 to_light = vsub(light_pos, position);
+				d3 light_dir = vnorm(to_light);
+				Ray shadow;
+				shadow.d = light_dir;
+				shadow.o = vadd(position, vscale(1e-4, light_dir));
+				shadow.tnear = 0;
+				shadow.tfar = (float)vlen(to_light);
+				n_shadow++;
+				Best dummy;
+				if (trace<true>(sc, shadow, stack, dummy))
+					continue;
+				c3 diff_col = diff_colour(light, *mat, light_dir, normal);
+				c3 spec_col = spec_colour(light, *mat, cam_dir, light_dir, normal);
+				light_total = cadd(light_total, cadd(diff_col, spec_col));
+			}
+			light_total = cscale((float)(1.0 / (double)(n * n)), light_total);
+			total = cadd(total, light_total);
+		}
+		// shading.c:70-112: children exist when the material reflects and the child's
+		// depth passes the cut at shading.c:120
+		if (mat->reflect > 0.0f && (int)depth + 1 <= sc.max_reflections)
+			n_children = (mat->glossiness <= 0.0f || depth > 1) ? 1 : sc.reflection_samples;
+	}
+
+	// Compact the spawning lanes: one slot reservation per wave.
+	if (io.queue_out) {
+		unsigned want = (unsigned)n_children;
+		unsigned prefix = want;
+		const unsigned lane = lane_id();
+		// inclusive prefix sum over the wave
+		for (int off = 1; off < 64; off <<= 1) {
+			unsigned v = __shfl_up(prefix, off, 64);
+			if (lane >= (unsigned)off)
+				prefix += v;
+		}
+		unsigned wave_total = __shfl(prefix, 63, 64);
+		if (wave_total) {
+			unsigned base = 0;
+			if (lane == 0)
+				base = atomicAdd(io.queue_count, wave_total);
+			base = __shfl(base, 0, 64);
+			unsigned my = base + prefix - want;
+			if (want) {
+				if (my + want > io.queue_capacity) {
+					atomicAdd(&io.counters->queue_overflow, 1ull);
+				} else {
+					// shading.c:81-84
+					double dn = vdot(ray.d, normal);
+					d3 rdir = vadd(ray.d, vscale(-2 * dn, normal));           // vector.c:77-81
+					d3 rorg = vadd(position, vscale(1e-2, rdir));
+					c3 w = cmul(lc3(mat->specular), { mat->reflect, mat->reflect, mat->reflect });
+					w = cmul(w, weight);
+					if (want == 1 && (mat->glossiness <= 0.0f || depth > 1)) {
+						QueueItem it;
+						it.o[0] = rorg.x; it.o[1] = rorg.y; it.o[2] = rorg.z;
+						it.d[0] = rdir.x; it.d[1] = rdir.y; it.d[2] = rdir.z;
+						it.weight[0] = w.r; it.weight[1] = w.g; it.weight[2] = w.b;
+						it.slot = slot; it.key = key_child(key, 0); it.depth = depth + 1;
+						it.pad[0] = it.pad[1] = 0;
+						io.queue_out[my] = it;
+					} else {
+						// shading.c:93-109
+						const float inv = (float)(1. / (double)sc.reflection_samples);
+						w = cscale(inv, w);
+						d3 pdir = vnorm(rdir);
+						const d3 n1 = { 1, 0, 0 }, n2 = { 0, 1, 0 };
+						d3 orth = (__builtin_fabs(vdot(pdir, n1)) < vlen(pdir) / 1.4142135623730950488016887242096980785696718753769480731766)
+								? vcross(pdir, n1) : vcross(pdir, n2);            // shading.c:60-68
+						d3 ta = vnorm(orth);
+						d3 tb = vnorm(vcross(pdir, ta));
+						for (unsigned i = 0; i < want; i++) {
+							double ra = keyed_drand(key, PURPOSE_GLOSSY, 2u * i);
+							double rb = keyed_drand(key, PURPOSE_GLOSSY, 2u * i + 1u);
+							d3 a = vscale((double)mat->glossiness * (2 * ra - 1), ta);
+							d3 b = vscale((double)mat->glossiness * (2 * rb - 1), tb);
+							d3 dir = vadd(pdir, vadd(a, b));
+							QueueItem it;
+							it.o[0] = rorg.x; it.o[1] = rorg.y; it.o[2] = rorg.z;
+							it.d[0] = dir.x; it.d[1] = dir.y; it.d[2] = dir.z;
+							it.weight[0] = w.r; it.weight[1] = w.g; it.weight[2] = w.b;
+							it.slot = slot; it.key = key_child(key, i); it.depth = depth + 1;
+							it.pad[0] = it.pad[1] = 0;
+							io.queue_out[my + i] = it;
+						}
+					}
+				}
+			}
+		}
+	}
+	return total;
+}
+
+// Sample index -> pixel.  Samples are numbered tile by tile over the tiles this
+// call owns, pixels row-major inside a tile, `spp` consecutive samples per pixel.
+struct TileMap {
+	int tile_w, tile_h, tiles_x, tiles_y;
+	int tile_first, tile_stride, owned;
+	int x0, y0, x1, y1;
+};
+
+DEV bool sample_to_pixel(const TileMap &tm, int spp, unsigned long long sample, int &px, int &py, int &k,
+		uint32_t &slot)
+{
+	unsigned long long pix = sample / (unsigned)spp;
+	k = (int)(sample - pix * (unsigned)spp);
+	unsigned per_tile = (unsigned)(tm.tile_w * tm.tile_h);
+	unsigned long long lt = pix / per_tile;
+	unsigned in_tile = (unsigned)(pix - lt * per_tile);
+	slot = (uint32_t)pix;
+	if (lt >= (unsigned long long)tm.owned)
+		return false;
+	int tile = tm.tile_first + (int)lt * tm.tile_stride;
+	int tx = tile % tm.tiles_x, ty = tile / tm.tiles_x;
+	px = tx * tm.tile_w + (int)(in_tile % (unsigned)tm.tile_w);
+	py = ty * tm.tile_h + (int)(in_tile / (unsigned)tm.tile_w);
+	return px >= tm.x0 && px < tm.x1 && py >= tm.y0 && py < tm.y1;
+}
+
+// ray.c:19-44 with the jitter of ray.c:47-59 or the pixel centre of ray.c:62-65
+DEV Ray camera_ray(const DevScene &sc, int i, int j, float offx, float offy)
+{
+	const int nx = sc.width, ny = sc.height;
+	float u = (float)(sc.cam_left + sc.cam_width * (double)((float)i + offx) / (double)nx);
+	float v = (float)(sc.cam_bottom + sc.cam_height * (double)((float)j + offy) / (double)ny);
+	float d = sc.cam_d;
+	Ray r;
+	r.o = ld3(sc.cam_pos);
+	r.d = vnorm(vadd(vscale((double)(-d), ld3(sc.cam_w)),
+				vadd(vscale((double)u, ld3(sc.cam_u)), vscale((double)v, ld3(sc.cam_v)))));
+	r.tnear = 0;
+	r.tfar = __builtin_huge_valf();
+	return r;
+}
+
+DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_table, uint32_t seed,
+		int px, int py, int k, uint32_t &key, float &offx, float &offy)
+{
+	uint32_t pixel = (uint32_t)(sc.width * py + px);
+	key = key0_of(seed, pixel, (uint32_t)k);
+	if (!sc.antialiasing) {
+		offx = 0.5f;
+		offy = 0.5f;
+		return;
+	}
+	const int aa = sc.aa_samples;
+	const float n = (float)aa;
+	int p = k % aa, q = k / aa;
+	double r0, r1;
+	if (rng_mode == RTAMD_RNG_GLIBC) {
+		// draw 2*((j*W+i)*aa^2+k)+{0,1} of the serial stream
+		unsigned long long idx = 2ull * ((unsigned long long)pixel * (unsigned)sc.spp + (unsigned)k);
+		r0 = (double)glibc_table[idx] / ((double)2147483647);
+		r1 = (double)glibc_table[idx + 1] / ((double)2147483647);
+	} else {
+		r0 = keyed_drand(key, PURPOSE_AA, 0);
+		r1 = keyed_drand(key, PURPOSE_AA, 1);
+	}
+	offx = (float)(((double)p + r0) / (double)n);
+	offy = (float)(((double)q + r1) / (double)n);
+}
+
+} // namespace
+
+// =============================================================================
+// Kernels
+// =============================================================================
+
+// Primary samples: camera ray, nearest hit, direct lighting with shadow rays,
+// environment lookup; children go to the bounce queue.  raytracer.c:32-54,78-84.
+__global__ void __launch_bounds__(RT_BLOCK)
+k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
+		int rng_mode, uint32_t seed, const int32_t *glibc_table, long long *accum,
+		rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count, unsigned queue_capacity,
+		DevCounters *counters)
+{
+	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
+	int *stack = s_stack + threadIdx.x;
+	unsigned long long local = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+	unsigned long long sample = sample_first + local;
+	int px = 0, py = 0, k = 0;
+	uint32_t slot = 0;
+	bool active = local < sample_count && sample_to_pixel(tm, sc.spp, sample, px, py, k, slot);
+
+	uint32_t key = 0;
+	Ray ray;
+	ray.o = { 0, 0, 0 }; ray.d = { 0, 0, 1 }; ray.tnear = 0; ray.tfar = 0;
+	if (active) {
+		float offx, offy;
+		sample_offsets(sc, rng_mode, glibc_table, seed, px, py, k, key, offx, offy);
+		ray = camera_ray(sc, px, py, offx, offy);
+	}
+	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters };
+	rtamd_hit_record *rec = nullptr;
+	if (hits && active) {
+		// window-local record index
+		unsigned long long wpix = (unsigned long long)(py - tm.y0) * (unsigned)(tm.x1 - tm.x0) + (unsigned)(px - tm.x0);
+		rec = hits + wpix * (unsigned)sc.spp + (unsigned)k;
+	}
+	unsigned n_shadow = 0, n_env = 0;
+	c3 weight = { 1.0f, 1.0f, 1.0f };
+	c3 total = shade_vertex(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env);
+
+	// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
+	// not depend on the order in which lanes, waves or later bounces arrive.
+	long long r = active ? to_fixed(total.r) : 0, g = active ? to_fixed(total.g) : 0,
+	     b = active ? to_fixed(total.b) : 0;
+	const unsigned lane = lane_id();
+	// segmented reduction over runs of lanes that share a pixel (runs are contiguous)
+	uint32_t seg = active ? slot : 0xffffffffu;
+	for (int off = 1; off < 64; off <<= 1) {
+		uint32_t oseg = __shfl_down(seg, off, 64);
+		long long orr = __shfl_down(r, off, 64), og = __shfl_down(g, off, 64), ob = __shfl_down(b, off, 64);
+		// lane + off belongs to my run only if every lane in between does, which holds
+		// for contiguous runs when its slot equals mine
+		if (lane + off < 64 && oseg == seg) {
+			r += orr; g += og; b += ob;
+		}
+	}
+	uint32_t prev = __shfl_up(seg, 1, 64);
+	bool head = active && (lane == 0 || prev != seg);
+	if (head) {
+		unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
+		if (r) atomicAdd(p + 0, (unsigned long long)r);
+		if (g) atomicAdd(p + 1, (unsigned long long)g);
+		if (b) atomicAdd(p + 2, (unsigned long long)b);
+	}
+	wave_count_add(&counters->rays_primary, active ? 1u : 0u);
+	wave_count_add(&counters->rays_shadow, n_shadow);
+	wave_count_add(&counters->env_lookups, n_env);
+}
+
+// One bounce: every queued ray is traced and shaded like a primary one
+// (shading.c:114-141 at depth >= 1) and its radiance, scaled by the path
+// weight, is added to its pixel.  Grid-stride over the queue population, which
+// is read from device memory so the host never waits between bounces.
+__global__ void __launch_bounds__(RT_BLOCK)
+k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count, unsigned queue_capacity,
+		long long *accum, QueueItem *queue_out, unsigned *queue_out_count, DevCounters *counters)
+{
+	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
+	int *stack = s_stack + threadIdx.x;
+	unsigned count = *queue_in_count;
+	if (count > queue_capacity)
+		count = queue_capacity;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		atomicMax(&counters->queue_peak, (unsigned long long)count);
+	const unsigned stride = gridDim.x * RT_BLOCK;
+	// every lane of a wave runs the same number of iterations (the wave-level
+	// compaction inside shade_vertex needs all 64 lanes present)
+	const unsigned rounds = (count + stride - 1) / stride;
+	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters };
+	unsigned n_shadow = 0, n_env = 0, n_rays = 0;
+	for (unsigned round = 0; round < rounds; round++) {
+		unsigned idx = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
+		bool active = idx < count;
+		Ray ray;
+		ray.o = { 0, 0, 0 }; ray.d = { 0, 0, 1 }; ray.tnear = 0; ray.tfar = 0;
+		c3 weight = { 0, 0, 0 };
+		uint32_t slot = 0, key = 0, depth = 0;
+		if (active) {
+			const QueueItem it = queue_in[idx];
+			ray.o = { it.o[0], it.o[1], it.o[2] };
+			ray.d = { it.d[0], it.d[1], it.d[2] };
+			ray.tnear = 0;
+			ray.tfar = __builtin_huge_valf();
+			weight = { it.weight[0], it.weight[1], it.weight[2] };
+			slot = it.slot; key = it.key; depth = it.depth;
+			n_rays++;
+		}
+		c3 total = shade_vertex(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env);
+		if (active)
+			accumulate(accum, slot, cmul(weight, total));
+	}
+	wave_count_add(&counters->rays_secondary, n_rays);
+	wave_count_add(&counters->rays_shadow, n_shadow);
+	wave_count_add(&counters->env_lookups, n_env);
+}
+
+// Accumulators -> the reference's float RGBA frame (raytracer.c:46,81): the
+// per-pixel sum is scaled by the float 1.0/aa^2 when antialiasing is on.
+__global__ void k_resolve(DevScene sc, TileMap tm, unsigned long long pixel_first, unsigned long long pixel_count,
+		const long long *accum, float *colour)
+{
+	unsigned long long local = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (local >= pixel_count)
+		return;
+	unsigned long long pix = pixel_first + local;
+	int px, py, k;
+	uint32_t slot;
+	if (!sample_to_pixel(tm, 1, pix, px, py, k, slot))
+		return;
+	const long long *a = accum + 3ull * slot;
+	float r = (float)((double)a[0] / RT_FIX_SCALE);
+	float g = (float)((double)a[1] / RT_FIX_SCALE);
+	float b = (float)((double)a[2] / RT_FIX_SCALE);
+	if (sc.antialiasing) {
+		float s = (float)(1.0 / (double)sc.spp);
+		r = s * r; g = s * g; b = s * b;
+	}
+	float4 out = { r, g, b, 0.0f };
+	reinterpret_cast<float4 *>(colour)[(unsigned long long)sc.width * py + px] = out;
+}
+
+// ray_intersect on a batch of caller-supplied rays (ray.h:25, ray.c:643-672).
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace(DevScene sc, const double *rays, unsigned long long n, rtamd_hit_record *hits)
+{
+	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
+	int *stack = s_stack + threadIdx.x;
+	unsigned long long i = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
+	if (i >= n)
+		return;
+	const double *p = rays + 8 * i;
+	Ray ray;
+	ray.o = { p[0], p[1], p[2] };
+	ray.d = { p[3], p[4], p[5] };
+	ray.tnear = (float)p[6];
+	ray.tfar = (float)p[7];
+	Best best;
+	rtamd_hit_record r;
+	r.surface = -1; r.triangle = -1; r.t = 0; r.pad = 0;
+	r.position[0] = r.position[1] = r.position[2] = 0;
+	r.normal[0] = r.normal[1] = r.normal[2] = 0;
+	if (trace<false>(sc, ray, stack, best)) {
+		d3 position, normal;
+		finish_hit(sc, ray, best, position, normal);
+		r.surface = best.surface;
+		if (best.ncode == NC_MESH) {
+			const DevMesh &mesh = sc.meshes[sc.surfaces[best.surface].mesh];
+			r.triangle = as_i(reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first)[3 * best.tri].w);
+		}
+		r.t = best.t;
+		r.position[0] = position.x; r.position[1] = position.y; r.position[2] = position.z;
+		r.normal[0] = normal.x; r.normal[1] = normal.y; r.normal[2] = normal.z;
+	}
+	hits[i] = r;
+}
+
+// camera_ray / camera_ray_aa for every sample of the selection (ray.h:23-24).
+__global__ void k_camera_rays(DevScene sc, TileMap tm, unsigned long long sample_count, int rng_mode,
+		uint32_t seed, const int32_t *glibc_table, double *rays)
+{
+	unsigned long long sample = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (sample >= sample_count)
+		return;
+	int px, py, k;
+	uint32_t slot;
+	if (!sample_to_pixel(tm, sc.spp, sample, px, py, k, slot))
+		return;
+	uint32_t key;
+	float offx, offy;
+	sample_offsets(sc, rng_mode, glibc_table, seed, px, py, k, key, offx, offy);
+	Ray ray = camera_ray(sc, px, py, offx, offy);
+	double *o = rays + 8 * (((unsigned long long)sc.width * py + px) * (unsigned)sc.spp + (unsigned)k);
+	o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z;
+	o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
+	o[6] = (double)ray.tnear; o[7] = (double)ray.tfar;
+}
+
+// Frame <-> dense per-owner tile buffer (multi-GPU framebuffer exchange).
+__global__ void k_tiles_copy(int width, int height, TileMap tm, float *frame, float *packed, int unpack)
+{
+	unsigned long long pix = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned per_tile = (unsigned)(tm.tile_w * tm.tile_h);
+	if (pix >= (unsigned long long)tm.owned * per_tile)
+		return;
+	int px, py, k;
+	uint32_t slot;
+	TileMap whole = tm;
+	whole.x0 = 0; whole.y0 = 0; whole.x1 = width; whole.y1 = height;
+	if (!sample_to_pixel(whole, 1, pix, px, py, k, slot))
+		return;
+	float4 *f = reinterpret_cast<float4 *>(frame) + (unsigned long long)width * py + px;
+	float4 *p = reinterpret_cast<float4 *>(packed) + pix;
+	if (unpack)
+		*f = *p;
+	else
+		*p = *f;
+}
+
+// =============================================================================
+// Host-side launchers (called from api.hip)
+// =============================================================================
+
+static TileMap make_tile_map(int width, int height, const rtamd_render_params &p)
+{
+	TileMap tm;
+	tm.tile_w = p.tile_w;
+	tm.tile_h = p.tile_h;
+	tm.tiles_x = (width + p.tile_w - 1) / p.tile_w;
+	tm.tiles_y = (height + p.tile_h - 1) / p.tile_h;
+	tm.tile_first = p.tile_first;
+	tm.tile_stride = p.tile_stride;
+	int total = tm.tiles_x * tm.tiles_y;
+	tm.owned = p.tile_first < total ? (total - p.tile_first + p.tile_stride - 1) / p.tile_stride : 0;
+	bool whole = p.x0 == 0 && p.y0 == 0 && p.x1 == 0 && p.y1 == 0;
+	tm.x0 = whole ? 0 : p.x0;
+	tm.y0 = whole ? 0 : p.y0;
+	tm.x1 = whole ? width : p.x1;
+	tm.y1 = whole ? height : p.y1;
+	return tm;
+}
+
+int rt_tiles_owned(int width, int height, const rtamd_render_params &p)
+{
+	return make_tile_map(width, height, p).owned;
+}
+
+unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_params &p)
+{
+	TileMap tm = make_tile_map(width, height, p);
+	return (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h);
+}
+
+hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
+		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
+		long long *accum, rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count,
+		unsigned queue_capacity, DevCounters *counters, hipStream_t stream)
+{
+	if (!sample_count)
+		return hipSuccess;
+	TileMap tm = make_tile_map(sc.width, sc.height, p);
+	unsigned long long blocks = (sample_count + RT_BLOCK - 1) / RT_BLOCK;
+	hipLaunchKernelGGL(k_primary, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm, sample_first,
+			sample_count, p.rng_mode, p.seed, glibc_table, accum, hits, queue_out, queue_count,
+			queue_capacity, counters);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
+		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
+		DevCounters *counters, unsigned grid_blocks, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_bounce, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, queue_in, queue_in_count,
+			queue_capacity, accum, queue_out, queue_out_count, counters);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
+		unsigned long long pixel_count, const long long *accum, float *colour, hipStream_t stream)
+{
+	if (!pixel_count)
+		return hipSuccess;
+	TileMap tm = make_tile_map(sc.width, sc.height, p);
+	unsigned long long blocks = (pixel_count + 255) / 256;
+	hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, stream, sc, tm, pixel_first, pixel_count,
+			accum, colour);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
+		rtamd_hit_record *hits, hipStream_t stream)
+{
+	if (!n)
+		return hipSuccess;
+	unsigned long long blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
+	hipLaunchKernelGGL(k_trace, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, rays, n, hits);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_camera_rays(const DevScene &sc, const rtamd_render_params &p,
+		const int32_t *glibc_table, double *rays, hipStream_t stream)
+{
+	TileMap tm = make_tile_map(sc.width, sc.height, p);
+	unsigned long long samples = (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h) * (unsigned)sc.spp;
+	if (!samples)
+		return hipSuccess;
+	unsigned long long blocks = (samples + 255) / 256;
+	hipLaunchKernelGGL(k_camera_rays, dim3((unsigned)blocks), dim3(256), 0, stream, sc, tm, samples, p.rng_mode,
+			p.seed, glibc_table, rays);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_tiles_copy(int width, int height, const rtamd_render_params &p, float *frame,
+		float *packed, int unpack, hipStream_t stream)
+{
+	TileMap tm = make_tile_map(width, height, p);
+	unsigned long long pixels = (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h);
+	if (!pixels)
+		return hipSuccess;
+	unsigned long long blocks = (pixels + 255) / 256;
+	hipLaunchKernelGGL(k_tiles_copy, dim3((unsigned)blocks), dim3(256), 0, stream, width, height, tm, frame,
+			packed, unpack);
+	return hipGetLastError();
+}

@@ -1,0 +1,124 @@
+/* Device-side scene layout (structure-of-arrays buffers in HBM) shared by the
+ * host flattening code and the HIP kernels.  Internal to librtamd. */
+#ifndef RTAMD_SCENE_DEV_H
+#define RTAMD_SCENE_DEV_H
+
+#include <stdint.h>
+#include "rtamd.h"
+
+#define RT_MAX_STACK 32        /* BVH traversal stack entries per lane (LDS) */
+#define RT_BLOCK 256           /* threads per workgroup: 4 wave64 */
+#define RT_FIX_SCALE 4294967296.0   /* 2^32: fixed-point scale of the accumulators */
+
+/* One placed shape (scene.h:60-67) with everything the intersectors need
+ * precomputed in the reference's own arithmetic (same operations, same order,
+ * so the bits are the ones the reference computes per ray). */
+struct DevSurface {
+	float bbox[6];             /* xmin ymin zmin xmax ymax zmax */
+	int32_t shape_type;
+	int32_t material;
+	int32_t mesh;
+	int32_t capped;
+	int32_t affine;            /* world_to_model row 3 is exactly (0,0,0,1) */
+	int32_t pad0;
+	float radius, height;
+	double w2m[16];            /* column-major, matrix.c:66 */
+	/* plane (ray.c:69-97): n = e1 x e2, axn = e1 x n, bxn = e2 x n, det = e1 . bxn */
+	double pn[3], paxn[3], pbxn[3];
+	float pdet;
+	float pad1;
+};
+
+struct DevMaterial {
+	float diffuse[3];
+	float specular[3];
+	int32_t shininess;
+	float reflect;
+	float glossiness;
+	int32_t pad;
+};
+
+struct DevLight {
+	int32_t type;
+	float intensity;
+	double position[3];
+	double edge1[3];
+	double edge2[3];
+	float colour[3];
+	float pad;
+};
+
+/* BVH node: two children with their boxes, 64 bytes, read as four float4.
+ *   q0 = lo0.x lo0.y lo0.z hi0.x
+ *   q1 = hi0.y hi0.z lo1.x lo1.y
+ *   q2 = lo1.z hi1.x hi1.y hi1.z
+ *   q3 = bits(child0) bits(child1) 0 0
+ * child >= 0: inner node index (relative to the mesh's first node);
+ * child <  0: leaf, v = ~child, first triangle = v >> 2, count = (v & 3) + 1. */
+struct DevBvhNode {
+	float q[16];
+};
+
+/* Leaf-ordered triangle: three float4 (v0, v1, v2); v0.w carries the bits of
+ * the triangle's index in the mesh's own triangle array. */
+struct DevTriangle {
+	float v[12];
+};
+
+struct DevMesh {
+	int32_t node_first;        /* into nodes[] */
+	int32_t tri_first;         /* into tris[] / normals[] */
+	int32_t root;              /* child reference of the root (leaf if < 0) */
+	int32_t num_triangles;
+};
+
+struct DevCubeFace {
+	int32_t width, height;
+	int64_t offset;            /* in float4 texels from texels[0] */
+};
+
+/* Everything a kernel needs, passed by value (fits the kernarg segment). */
+struct DevScene {
+	int32_t width, height;
+	int32_t antialiasing, aa_samples;
+	int32_t shadow_samples, reflection_samples;
+	int32_t max_reflections;
+	int32_t spp;
+	double cam_pos[3], cam_u[3], cam_v[3], cam_w[3];
+	/* image-plane extents from cam_ray_internal (ray.c:27-30) for the two
+	 * `near` values the drivers pass (raytracer.c:43,49), computed on the host
+	 * because they involve tan() */
+	double cam_width, cam_left, cam_height, cam_bottom;
+	float cam_d;               /* `d = near` narrowed to float, ray.c:32 */
+	float background[3];
+	int32_t num_lights, num_surfaces, has_cubemap, any_reflective;
+	const DevLight *lights;
+	const DevSurface *surfaces;
+	const DevMaterial *materials;
+	const DevMesh *meshes;
+	const DevBvhNode *nodes;
+	const DevTriangle *tris;
+	const DevTriangle *normals; /* same order as tris: n0, n1, n2 */
+	const float *texels;        /* float4 RGBA */
+	DevCubeFace faces[6];
+};
+
+/* A ray waiting in a bounce queue. */
+struct QueueItem {
+	double o[3];
+	double d[3];
+	float weight[3];
+	uint32_t slot;              /* accumulator slot (pixel) */
+	uint32_t key;               /* keyed-RNG path key */
+	uint32_t depth;
+	uint32_t pad[2];
+};
+
+struct DevCounters {
+	unsigned long long rays_primary, rays_shadow, rays_secondary, env_lookups;
+	unsigned long long queue_overflow;
+	unsigned long long queue_peak;
+	unsigned long long pad[2];
+};
+
+#endif
