@@ -738,9 +738,16 @@ static int ray_surface_intersect(Ctx *c, Ray ray, int si, Hit *hit)
 	case RTAMD_SHAPE_CONE:
 		hits = ray_cone_intersect(tray, surf, ts, tnormals);
 		break;
-	case RTAMD_SHAPE_MESH:
-		hits = ray_mesh_intersect(tray, &c->s->meshes[surf->mesh], ts, tnormals, &triangle);
+	case RTAMD_SHAPE_MESH: {
+		const OMesh *mesh = &c->s->meshes[surf->mesh];
+		int levels = 0;
+		while ((4 << levels) < mesh->nt)
+			levels++;
+		c->st.mesh_probes++;
+		c->st.mesh_probe_levels += (uint64_t)levels;
+		hits = ray_mesh_intersect(tray, mesh, ts, tnormals, &triangle);
 		break;
+	}
 	default:
 		return 0;
 	}
@@ -1179,6 +1186,8 @@ static void add_stats(oracle_stats *a, const oracle_stats *b)
 	a->draws += b->draws;
 	a->bbox_tests += b->bbox_tests;
 	a->surface_probes += b->surface_probes;
+	a->mesh_probes += b->mesh_probes;
+	a->mesh_probe_levels += b->mesh_probe_levels;
 }
 
 int oracle_render(const oracle_scene *s, uint32_t seed, int rng_mode, int x0, int y0, int x1,

@@ -34,6 +34,8 @@ typedef struct oracle_stats {
 	uint64_t draws;            /* drand() calls */
 	uint64_t bbox_tests;       /* ray_bbox_test calls */
 	uint64_t surface_probes;   /* ray_surface_intersect calls */
+	uint64_t mesh_probes;      /* ... of which on a mesh surface */
+	uint64_t mesh_probe_levels;/* sum over mesh probes of ceil(log2(triangles / 4)) */
 } oracle_stats;
 
 /* Builds the oracle's own acceleration structure (a plain double-precision

@@ -104,12 +104,14 @@ int main(int argc, char **argv)
 	printf("{\"seconds\": %.6f, \"rays\": %llu, \"rays_primary\": %llu, \"rays_shadow\": %llu, "
 			"\"rays_secondary\": %llu, \"env_lookups\": %llu, \"light_samples\": %llu, "
 			"\"draws\": %llu, \"bbox_tests\": %llu, \"surface_probes\": %llu, "
+			"\"mesh_probes\": %llu, \"mesh_probe_levels\": %llu, "
 			"\"threads\": %d, \"mrays_per_s\": %.6f}\n",
 			t1 - t0, rays, (unsigned long long)st.rays_primary,
 			(unsigned long long)st.rays_shadow, (unsigned long long)st.rays_secondary,
 			(unsigned long long)st.env_lookups, (unsigned long long)st.light_samples,
 			(unsigned long long)st.draws, (unsigned long long)st.bbox_tests,
-			(unsigned long long)st.surface_probes, threads, rays / (t1 - t0) / 1e6);
+			(unsigned long long)st.surface_probes, (unsigned long long)st.mesh_probes,
+			(unsigned long long)st.mesh_probe_levels, threads, rays / (t1 - t0) / 1e6);
 	oracle_scene_destroy(s);
 	return 0;
 }

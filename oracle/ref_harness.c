@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "colour.h"
 #include "ray.h"
@@ -306,6 +307,8 @@ static int cmd_render(int argc, char **argv)
 	Camera *cam = scene->camera;
 	size_t sidx = 0;
 
+	struct timespec ts0, ts1;
+	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	srand(seed);
 	for (int j = 0; j < height; j++)
 		for (int i = 0; i < width; i++) {
@@ -350,8 +353,10 @@ static int cmd_render(int argc, char **argv)
 			}
 			buffer[width * j + i] = c;
 		}
+	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	/* The next value of the stream tells a test how many draws were made. */
 	printf("next_rand %d\n", rand());
+	printf("render_seconds %.6f\n", (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec));
 
 	write_file(prefix, ".colour.f32", buffer, (size_t)width * height * sizeof(Colour));
 	if (hits)

@@ -17,7 +17,7 @@ HIT_DTYPE = np.dtype([("surface", "<i4"), ("triangle", "<i4"), ("t", "<f4"), ("p
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("rays_primary", "rays_shadow", "rays_secondary", "env_lookups", "light_samples",
-                 "draws", "bbox_tests", "surface_probes")]
+                 "draws", "bbox_tests", "surface_probes", "mesh_probes", "mesh_probe_levels")]
 
     @property
     def rays(self):

@@ -1,0 +1,298 @@
+"""Host front end: SDL import with DTD defaults, OBJ and PNG readers, the blob,
+the rand() stream and the PPM quantiser.  No GPU."""
+import hashlib
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from raytracer_amd import _abi
+from conftest import ASSETS, ROOT, load_golden, scene_path
+
+
+def write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+MINIMAL = """<?xml version='1.0'?>
+<!DOCTYPE Sdl SYSTEM "sdl.dtd">
+<Sdl>
+ <Config />
+ <Cameras><Camera position="0 0 5" direction="0 0 -1" up="0 1 0" fovy="60" name="c"/></Cameras>
+ <Lights><PointLight position="0 5 5" name="l"/></Lights>
+ <Geometry><Sphere radius="1" name="s"/>{geometry}</Geometry>
+ <Materials><Material diffuse_color="1 0 0" name="m"/></Materials>
+ <Scene camera="c" lights="l">{scene}</Scene>
+</Sdl>
+"""
+
+
+def test_dtd_defaults(tmp_path):
+    """sdl.dtd:6-15,26,36-37,111-114,123-124"""
+    p = write(tmp_path, "a.sdl", MINIMAL.format(geometry="", scene='<Shape geometry="s" material="m"/>'))
+    b = ra.load_sdl(p)
+    h = b.header
+    assert (h.width, h.height, h.antialiasing, h.aa_samples) == (512, 512, 0, 4)
+    assert (h.shadow_samples, h.reflection_samples, h.max_reflections) == (9, 10, 5)
+    assert h.cam_near_plane == 1.0
+    assert list(h.background)[:3] == [0.0, 0.0, 0.0] and h.has_cubemap == 0
+    light = b.lights[0]
+    assert light.intensity == 1.0 and list(light.colour)[:3] == [1.0, 1.0, 1.0]
+    m = b.materials[0]
+    assert list(m.specular)[:3] == [1.0, 1.0, 1.0]
+    assert (m.shininess, m.reflect, m.glossiness) == (100, 0.0, 0.0)
+    assert b.spp == 1
+
+
+def test_camera_basis_matches_reference_formula():
+    """scene.c:113-117 on 3-aa.sdl: w = -normalize(dir), u = normalize(up x w), v = w x u"""
+    b = ra.load_sdl(scene_path("3-aa"))
+    d = np.array([0, -4, -8], np.float32).astype(np.float64)
+    w = -(d * (1 / np.sqrt(d @ d)))
+    up = np.array([0.0, 1.0, 0.0])
+    u = np.cross(up, w)
+    u = u * (1 / np.sqrt(u @ u))
+    v = np.cross(w, u)
+    assert np.array_equal(np.array(b.header.cam_w), w)
+    assert np.array_equal(np.array(b.header.cam_u), u)
+    assert np.array_equal(np.array(b.header.cam_v), v)
+
+
+def test_surface_order_is_reverse_document_order():
+    """scene.c:342-343 prepends each surface"""
+    b = ra.load_sdl(scene_path("5-primitives"))
+    types = [s.shape_type for s in b.surfaces]
+    # document order: sphere, teapot(mesh), cone, cylinder, plane, disk
+    assert types == [_abi.SHAPE_DISK, _abi.SHAPE_PLANE, _abi.SHAPE_CYLINDER, _abi.SHAPE_CONE,
+                     _abi.SHAPE_MESH, _abi.SHAPE_SPHERE]
+
+
+def test_only_first_scene_child_is_imported(tmp_path):
+    """scene.c:586"""
+    scene = ('<Translate vector="1 2 3"><Shape geometry="s" material="m"/></Translate>'
+             '<Shape geometry="s" material="m"/>')
+    b = ra.load_sdl(write(tmp_path, "a.sdl", MINIMAL.format(geometry="", scene=scene)))
+    assert b.header.num_surfaces == 1
+    m = np.array(b.surfaces[0].model_to_world).reshape(4, 4).T
+    assert list(m[:3, 3]) == [1.0, 2.0, 3.0]
+    inv = np.array(b.surfaces[0].world_to_model).reshape(4, 4).T
+    assert list(inv[:3, 3]) == [-1.0, -2.0, -3.0]
+
+
+def test_transform_stack_and_padded_bbox(tmp_path):
+    """scene.c:373-419 (M' = M*T, inverse = T^-1 * M^-1) and scene.c:485-525"""
+    scene = ('<Translate vector="1 0 0"><Scale scale="2 2 2">'
+             '<Shape geometry="s" material="m"/></Scale></Translate>')
+    b = ra.load_sdl(write(tmp_path, "a.sdl", MINIMAL.format(geometry="", scene=scene)))
+    s = b.surfaces[0]
+    m = np.array(s.model_to_world).reshape(4, 4).T
+    inv = np.array(s.world_to_model).reshape(4, 4).T
+    assert np.allclose(m @ inv, np.eye(4))
+    assert np.array_equal(m, np.array([[2, 0, 0, 1], [0, 2, 0, 0], [0, 0, 2, 0], [0, 0, 0, 1.0]]))
+    lo = np.float32(np.float32(-1.0) - 1e-3)
+    hi = np.float32(np.float32(1.0) + 1e-3)
+    want = [np.float32(2 * float(lo) + 1), np.float32(2 * float(lo)), np.float32(2 * float(lo)),
+            np.float32(2 * float(hi) + 1), np.float32(2 * float(hi)), np.float32(2 * float(hi))]
+    assert list(s.bbox) == [float(x) for x in want]
+
+
+def test_rotation_matrix_is_quaternion_form(tmp_path):
+    """matrix.c:215-228, quaternion.c:88-108,180-197"""
+    scene = '<Rotate axis="1 1 1" angle="78"><Shape geometry="s" material="m"/></Rotate>'
+    b = ra.load_sdl(write(tmp_path, "a.sdl", MINIMAL.format(geometry="", scene=scene)))
+    angle = 78.0 * 6.283185307179586476925287 / 360.0
+    l = np.sqrt(3.0)
+    s_, c_ = np.sin(angle / 2), np.cos(angle / 2)
+    w, x, y, z = c_, s_ * 1 / l, s_ * 1 / l, s_ * 1 / l
+    want = np.array([
+        [w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+        [2 * x * y + 2 * w * z, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x],
+        [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, w * w - x * x - y * y + z * z]])
+    m = np.array(b.surfaces[0].model_to_world).reshape(4, 4).T
+    assert np.array_equal(m[:3, :3], want)
+
+
+def test_light_names_match_by_prefix_last_wins(tmp_path):
+    """scene.c:316-318: strncmp over the requested length, no break"""
+    text = MINIMAL.format(geometry="", scene='<Shape geometry="s" material="m"/>')
+    text = text.replace('<PointLight position="0 5 5" name="l"/>',
+                        '<PointLight position="1 0 0" name="lamp"/>'
+                        '<PointLight position="2 0 0" name="lamp2"/>')
+    text = text.replace('lights="l"', 'lights="lamp"')
+    b = ra.load_sdl(write(tmp_path, "a.sdl", text))
+    assert b.header.num_lights == 1
+    assert list(b.lights[0].position) == [2.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("scene,msg", [
+    ('<Shape geometry="nope" material="m"/>', "Requested shape"),
+    ('<Shape geometry="s" material="nope"/>', "Requested material"),
+    ('<Shape geometry="s"/>', "no material"),
+    ('<Shape geometry="s" material="m" texture="t"/>', "no texture support"),
+    ('<Bend><Shape geometry="s" material="m"/></Bend>', "Unknown node"),
+])
+def test_scene_errors(tmp_path, scene, msg):
+    """error paths of scene.c:349-368,401-405"""
+    with pytest.raises(_abi.RtamdError) as e:
+        ra.load_sdl(write(tmp_path, "a.sdl", MINIMAL.format(geometry="", scene=scene)))
+    assert msg in str(e.value)
+
+
+def test_missing_files():
+    with pytest.raises(_abi.RtamdError):
+        ra.load_sdl("/nonexistent/scene.sdl")
+    # showcase.sdl as shipped names a cubemap that is not in the reference tree
+    with pytest.raises(_abi.RtamdError) as e:
+        ra.load_sdl(os.path.join(ASSETS, "showcase.sdl"))
+    assert "creek_negative_x.png" in str(e.value)
+
+
+def test_all_loadable_reference_scenes():
+    sizes = {"1-phong": (512, 512, 1), "2-transform": (512, 512, 1), "3-aa": (512, 512, 64),
+             "4-environmentmap": (512, 512, 16), "5-primitives": (1024, 512, 1),
+             "6-soft": (1024, 512, 16), "7-reflections": (640, 640, 25), "8-glossy": (640, 640, 25),
+             "cornell": (500, 500, 1), "showcase-uffizi": (512, 512, 1),
+             "showcase-4k": (3840, 2160, 64)}
+    for name, (w, h, spp) in sizes.items():
+        b = ra.load_sdl(scene_path(name))
+        assert (b.width, b.height, b.spp) == (w, h, spp), name
+    b = ra.load_sdl(scene_path("showcase-4k"))
+    v, n, t = b.mesh_arrays(0)
+    # teapot.obj / tablecloth.obj sizes
+    counts = sorted((b.meshes[i].num_vertices, b.meshes[i].num_triangles) for i in range(2))
+    assert counts == [(5218, 10118), (12096, 4032)]
+    assert b.fixed_rng_consumption() is False
+    assert ra.load_sdl(scene_path("3-aa")).fixed_rng_consumption() is True
+
+
+def test_obj_values_are_float_rounded(tmp_path):
+    """wavefrontobj.l:69-72: (float)atof before widening to double (mesh.c:93-95)"""
+    obj = tmp_path / "t.obj"
+    obj.write_text("# c\nv 0.1 0.2 0.3\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0.5 0.5\n"
+                   "g grp\ns off\nf 1//1 2//1 3//1\nf 1/1/1 3/1/1 2/1/1\n")
+    text = MINIMAL.format(geometry=f'<Mesh src="{obj}" name="t"/>',
+                          scene='<Shape geometry="t" material="m"/>')
+    b = ra.load_sdl(write(tmp_path, "a.sdl", text))
+    v, n, t = b.mesh_arrays(0)
+    assert v[0, 0] == float(np.float32(0.1)) and v[0, 0] != 0.1
+    assert t.tolist() == [[0, 1, 2, 0, 0, 0], [0, 2, 1, 0, 0, 0]]
+
+
+@pytest.mark.parametrize("body,msg", [
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n", "more than three"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 9//1\n", "out of range"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 0//1\n", "Error parsing"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", "normal"),
+])
+def test_obj_errors(tmp_path, body, msg):
+    obj = tmp_path / "t.obj"
+    obj.write_text(body)
+    text = MINIMAL.format(geometry=f'<Mesh src="{obj}" name="t"/>',
+                          scene='<Shape geometry="t" material="m"/>')
+    with pytest.raises(_abi.RtamdError) as e:
+        ra.load_sdl(write(tmp_path, "a.sdl", text))
+    assert msg in str(e.value)
+
+
+def _decode_png_with_zlib(path):
+    """Independent PNG decode (zlib + the five filters) for 8-bit RGB."""
+    data = open(path, "rb").read()
+    pos, idat, w, h, bpp = 8, b"", 0, 0, 3
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert depth == 8 and ctype in (2, 6)
+            bpp = 3 if ctype == 2 else 4
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = zlib.decompress(idat)
+    stride = w * bpp
+    out = np.zeros((h, stride), np.uint8)
+    for y in range(h):
+        f = raw[y * (stride + 1)]
+        line = np.frombuffer(raw, np.uint8, stride, y * (stride + 1) + 1).astype(int)
+        up = out[y - 1].astype(int) if y else np.zeros(stride, int)
+        cur = np.zeros(stride, int)
+        for x in range(stride):
+            a = cur[x - bpp] if x >= bpp else 0
+            b = up[x]
+            c = up[x - bpp] if x >= bpp else 0
+            if f == 0:
+                p = 0
+            elif f == 1:
+                p = a
+            elif f == 2:
+                p = b
+            elif f == 3:
+                p = (a + b) // 2
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+            cur[x] = (line[x] + p) & 255
+        out[y] = cur
+    return out.reshape(h, w, bpp)
+
+
+def test_cubemap_texels_match_independent_png_decode():
+    """texture.c:16-51 + colour.c:41-57: rows flipped, value = u8 / 255. narrowed to float"""
+    b = ra.load_sdl(scene_path("4-environmentmap"))
+    faces = b.cubemap_faces()
+    names = ["negative_x", "positive_x", "negative_y", "positive_y", "negative_z", "positive_z"]
+    for f in (0, 3):
+        px = _decode_png_with_zlib(os.path.join(ASSETS, "cubemap", f"uffizi_gallery_{names[f]}.png"))
+        want = (px[::-1, :, :3].astype(np.float64) / 255.0).astype(np.float32)
+        assert np.array_equal(faces[f][..., :3], want)
+        assert np.all(faces[f][..., 3] == 1.0)
+
+
+def test_glibc_rand_stream_matches_libc_samples():
+    """raytracer.c:74 + ray.c:14-17: values recorded from libc's srand/rand"""
+    g = load_golden("glibc_rand")
+    for key in g.files:
+        seed = int(key.split("_")[1])
+        want = g[key]
+        assert np.array_equal(ra.glibc_rand(seed, 0, len(want)), want), key
+        assert np.array_equal(ra.glibc_rand(seed, 123, 50), want[123:173])
+    assert ra.glibc_rand(0x20071208, 0, 6).tolist() == [
+        550090280, 1662764947, 1694701646, 637131262, 587969062, 225625018]
+
+
+def test_quantiser_truncates_and_flips(tmp_path):
+    """ppm.c:16-24"""
+    c = np.zeros((2, 3, 4), np.float32)
+    c[0, 0, :3] = [0.5, 1.0, 2.0]           # bottom row -> last PPM row
+    c[1, 2, :3] = [-0.2, 0.999, 0.00392]    # top row -> first PPM row
+    q = ra.quantise_rgb8(c)
+    assert q[1, 0].tolist() == [127, 255, 255]
+    assert q[0, 2].tolist() == [0, 254, 0]
+    p = str(tmp_path / "x.ppm")
+    ra.ppm_write(c, p)
+    data = open(p, "rb").read()
+    assert data.startswith(b"P6\n3 2\n255\n")
+    assert data[len(b"P6\n3 2\n255\n"):] == q.tobytes()
+
+
+def test_blob_validation_rejects_corruption():
+    b = ra.load_sdl(scene_path("1-phong"))
+    raw = bytearray(b.tobytes())
+    ra.SceneBlob(bytes(raw))
+    bad = bytearray(raw)
+    bad[0] ^= 0xFF
+    with pytest.raises(_abi.RtamdError):
+        ra.SceneBlob(bytes(bad))
+    with pytest.raises(_abi.RtamdError):
+        ra.SceneBlob(bytes(raw[:-8]))
+    # a triangle index beyond the vertex array
+    bad = bytearray(raw)
+    off = b.meshes[0].off_triangle
+    bad[off:off + 4] = struct.pack("<i", 10 ** 6)
+    with pytest.raises(_abi.RtamdError):
+        ra.SceneBlob(bytes(bad))
