@@ -226,6 +226,8 @@ typedef struct rtamd_render_stats {
 	float ms_primary;               /* device time of the primary/shade kernel(s) */
 	int32_t launches_primary;
 	int32_t launches_bounce;
+	uint64_t bvh_nodes;             /* BVH nodes visited / triangle tests made; only */
+	uint64_t tri_tests;             /* counted by builds with -DRT_TRAVERSAL_STATS */
 } rtamd_render_stats;
 
 /* Replaces the pixel loop raytracer.c:78-84 + pixel_colour (raytracer.c:32-54)

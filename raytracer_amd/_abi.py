@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librtamd.so")
+# RTAMD_LIB selects another build of the same library (A/B measurements).
+LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "csrc", "librtamd.so")
 
 RTAMD_BLOB_MAGIC = 0x314353444D415452
 RTAMD_MAX_LIGHTS = 8
@@ -94,7 +95,8 @@ class RenderStats(C.Structure):
                 ("rays_secondary", C.c_uint64), ("env_lookups", C.c_uint64),
                 ("queue_peak", C.c_uint64), ("samples", C.c_uint64),
                 ("ms_total", C.c_float), ("ms_primary", C.c_float),
-                ("launches_primary", C.c_int32), ("launches_bounce", C.c_int32)]
+                ("launches_primary", C.c_int32), ("launches_bounce", C.c_int32),
+                ("bvh_nodes", C.c_uint64), ("tri_tests", C.c_uint64)]
 
 
 # Every symbol include/rtamd.h declares, with its prototype.

@@ -555,7 +555,8 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			launches_bounce++;
 		}
 	}
-	HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), stream));
+	HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), sc->d_counters,
+			stream));
 
 	if (stats) {
 		std::memset(stats, 0, sizeof *stats);
@@ -580,6 +581,8 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		stats->rays_secondary = c.rays_secondary;
 		stats->env_lookups = c.env_lookups;
 		stats->queue_peak = c.queue_peak;
+		stats->bvh_nodes = c.bvh_nodes;
+		stats->tri_tests = c.tri_tests;
 		stats->samples = samples;
 		stats->launches_primary = launches_primary;
 		stats->launches_bounce = launches_bounce;

@@ -118,7 +118,8 @@ struct DevCounters {
 	unsigned long long rays_primary, rays_shadow, rays_secondary, env_lookups;
 	unsigned long long queue_overflow;
 	unsigned long long queue_peak;
-	unsigned long long pad[2];
+	unsigned long long bvh_nodes;      /* only counted in RT_TRAVERSAL_STATS builds */
+	unsigned long long tri_tests;
 };
 
 #endif
