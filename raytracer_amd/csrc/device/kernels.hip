@@ -525,9 +525,183 @@ DEV bool mesh_traverse(const DevScene &sc, const DevMesh &mesh, d3 o, d3 d, floa
 	return found;
 }
 
-// ---- ray.c:483-578 + 643-672 ---------------------------------------------------
+// ---- packet traversal ---------------------------------------------------------
+//
+// The lanes of a wave that reach a mesh together (64 samples of one pixel, or
+// their shadow rays towards the same light) walk the BVH as ONE packet: the node
+// and triangle being examined are wave-uniform, so they are fetched through the
+// scalar data cache once per wave (constant address space -> s_load) instead of
+// once per lane through the vector L1, which is the unit this kernel saturates
+// when every lane fetches its own 64-byte node (measured: texture-data unit 96 %
+// busy).  The wave keeps one stack of child references in LDS; each lane keeps
+// one bit per stack level saying whether its own ray has to visit that entry.
+// Results are per lane and identical to the per-lane traversal: every triangle
+// whose leaf box a lane's ray may touch inside its window is tested by that
+// lane with the same arithmetic.
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f4v *const_f4;
+
+DEV const_f4 as_const(const void *p)
+{
+	return (const_f4)(unsigned long long)p;
+}
+
+DEV float4 cload(const_f4 p, int i)
+{
+	const f4v v = p[i];
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// Float ray for the packet box tests: rounded origin `of`, reciprocal direction,
+// and c = -(o - of)/d, which puts the part of the origin lost in the rounding
+// back into each slab distance: t = (plane - of) * i + c.  What remains is
+// rounding of the operations themselves, covered by a relative margin on the
+// entry/exit distances plus the absolute term e.
+struct PacketRay {
+	float ox, oy, oz;
+	float ix, iy, iz;
+	float cx, cy, cz;
+	float e;
+};
+
+DEV PacketRay make_packet_ray(d3 o, d3 d)
+{
+	PacketRay r;
+	float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+	if (__builtin_fabsf(fx) < 1e-30f) fx = __builtin_copysignf(1e-30f, fx);
+	if (__builtin_fabsf(fy) < 1e-30f) fy = __builtin_copysignf(1e-30f, fy);
+	if (__builtin_fabsf(fz) < 1e-30f) fz = __builtin_copysignf(1e-30f, fz);
+	r.ix = 1.0f / fx; r.iy = 1.0f / fy; r.iz = 1.0f / fz;
+	r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
+	float rx = (float)(o.x - (double)r.ox), ry = (float)(o.y - (double)r.oy), rz = (float)(o.z - (double)r.oz);
+	r.cx = -rx * r.ix; r.cy = -ry * r.iy; r.cz = -rz * r.iz;
+	// 2^-40 of the largest |o * (1/d)|: the absolute error left in a slab distance
+	// when (plane - of) * i and c cancel
+	float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.ox * r.ix), __builtin_fabsf(r.oy * r.iy)),
+			__builtin_fabsf(r.oz * r.iz));
+	r.e = m * 9.094947e-13f;
+	return r;
+}
+
+DEV bool packet_box_test(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+		float tlo, float thi, float &tn)
+{
+	const float margin = 9.5367431640625e-7f;   // 2^-20
+	float ax = __builtin_fmaf(lox - r.ox, r.ix, r.cx), bx = __builtin_fmaf(hix - r.ox, r.ix, r.cx);
+	float ay = __builtin_fmaf(loy - r.oy, r.iy, r.cy), by = __builtin_fmaf(hiy - r.oy, r.iy, r.cy);
+	float az = __builtin_fmaf(loz - r.oz, r.iz, r.cz), bz = __builtin_fmaf(hiz - r.oz, r.iz, r.cz);
+	float tnn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+	float tff = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+	tnn = __builtin_fmaf(-__builtin_fabsf(tnn), margin, tnn - r.e);
+	tff = __builtin_fmaf(__builtin_fabsf(tff), margin, tff + r.e);
+	tn = __builtin_fmaxf(tnn, tlo);
+	float tf = __builtin_fminf(tff, thi);
+	return tn <= tf;
+}
 
 template <bool ANYHIT>
+DEV bool mesh_traverse_packet(const DevScene &sc, const DevMesh &mesh, d3 o, d3 d, float tnear, float tfar,
+		int *wstack, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
+{
+	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
+	const const_f4 tris = as_const(sc.tris + mesh.tri_first);
+	const PacketRay pr = make_packet_ray(o, d);
+	const double dnear = (double)tnear, dfar = (double)tfar;
+	bool found = false;
+	best_t = __builtin_huge_val();
+	best_orig = -1;
+	best_tri = -1;
+	float limit = tfar;
+	unsigned trail = 0;          // bit k: this lane's ray must visit stack entry k
+	int sp = 0;                  // wave-uniform
+	int ref = __builtin_amdgcn_readfirstlane(mesh.root);
+	bool act = true;             // this lane's ray must visit `ref`
+	for (;;) {
+		if (ref >= 0) {
+			RT_STAT(if (lane_id() == 0) atomicAdd(&g_stat_nodes, 1ull));
+			const float4 q0 = cload(nodes, 4 * ref + 0), q1 = cload(nodes, 4 * ref + 1);
+			const float4 q2 = cload(nodes, 4 * ref + 2), q3 = cload(nodes, 4 * ref + 3);
+			float tn0, tn1;
+			bool h0 = packet_box_test(pr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0) && act;
+			bool h1 = packet_box_test(pr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1) && act;
+			const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1);
+			const int c0 = as_i(q3.x), c1 = as_i(q3.y);
+			if (m0 != 0 && m1 != 0) {
+				bool swap = false;
+				if (!ANYHIT) {
+					// front-to-back for the majority of the lanes
+					unsigned long long want1 = __builtin_amdgcn_ballot_w64(h1 && (!h0 || tn1 < tn0));
+					unsigned long long want0 = __builtin_amdgcn_ballot_w64(h0 && (!h1 || tn0 <= tn1));
+					swap = __builtin_popcountll(want1) > __builtin_popcountll(want0);
+				}
+				const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+				const bool hn = swap ? h1 : h0, hf = swap ? h0 : h1;
+				wstack[sp] = farc;
+				trail = hf ? (trail | (1u << sp)) : (trail & ~(1u << sp));
+				sp++;
+				ref = nearc;
+				act = hn;
+				continue;
+			} else if (m0 != 0) {
+				ref = c0;
+				act = h0;
+				continue;
+			} else if (m1 != 0) {
+				ref = c1;
+				act = h1;
+				continue;
+			}
+		} else {
+			const int v = ~ref;
+			const int first = v >> 2, count = (v & 3) + 1;
+			for (int i = 0; i < count; i++) {
+				const float4 p0 = cload(tris, 3 * (first + i) + 0);
+				const float4 p1 = cload(tris, 3 * (first + i) + 1);
+				const float4 p2 = cload(tris, 3 * (first + i) + 2);
+				float aa, bb, cc;
+				double t;
+				RT_STAT(if (lane_id() == 0) atomicAdd(&g_stat_tris, 1ull));
+				if (!act || !triangle_intersect(o, d, p0, p1, p2, aa, bb, cc, t))
+					continue;
+				int orig = as_i(p0.w);
+				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
+					best_t = t;
+					best_orig = orig;
+					best_tri = first + i;
+					ba = aa; bb_ = bb; bc = cc;
+					found = true;
+					if (ANYHIT) {
+						act = false;
+					} else {
+						float ft = (float)t;
+						if ((double)ft < t)
+							ft = next_up(ft);
+						limit = ft < tfar ? ft : tfar;
+					}
+				}
+			}
+		}
+		// next stack entry that some lane still has to visit
+		bool any = false;
+		while (sp > 0) {
+			sp--;
+			act = ((trail >> sp) & 1u) != 0 && !(ANYHIT && found);
+			if (__builtin_amdgcn_ballot_w64(act) != 0) {
+				ref = __builtin_amdgcn_readfirstlane(wstack[sp]);
+				any = true;
+				break;
+			}
+		}
+		if (!any)
+			break;
+	}
+	return found;
+}
+
+// ---- ray.c:483-578 + 643-672 ---------------------------------------------------
+
+template <bool ANYHIT, bool PACKET>
 DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 {
 	best.surface = -1;
@@ -554,8 +728,12 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 		default: {
 			int orig;
 			double t;
-			hits = mesh_traverse<ANYHIT>(sc, sc.meshes[s.mesh], o, d, bnear, bfar, stack,
-					tri, orig, t, ba, bb, bc) ? 1 : 0;
+			if (PACKET)
+				hits = mesh_traverse_packet<ANYHIT>(sc, sc.meshes[s.mesh], o, d, bnear, bfar, stack,
+						tri, orig, t, ba, bb, bc) ? 1 : 0;
+			else
+				hits = mesh_traverse<ANYHIT>(sc, sc.meshes[s.mesh], o, d, bnear, bfar, stack,
+						tri, orig, t, ba, bb, bc) ? 1 : 0;
 			ts[0] = (float)t;                       // ray.c:471
 			nc[0] = NC_MESH;
 			break;
@@ -742,6 +920,7 @@ struct ShadeIO {
 	DevCounters *counters;
 };
 
+template <bool PACKET>
 DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t key, c3 weight,
 		uint32_t slot, bool active, int *stack, rtamd_hit_record *rec,
 		unsigned &n_shadow, unsigned &n_env)
@@ -752,7 +931,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	bool hit = false;
 	d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
 	if (active) {
-		hit = trace<false>(sc, ray, stack, best);
+		hit = trace<false, PACKET>(sc, ray, stack, best);
 		if (hit)
 			finish_hit(sc, ray, best, position, normal);
 	}
@@ -810,7 +989,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 				shadow.tfar = (float)vlen(to_light);
 				n_shadow++;
 				Best dummy;
-				if (trace<true>(sc, shadow, stack, dummy))
+				if (trace<true, PACKET>(sc, shadow, stack, dummy))
 					continue;
 				c3 diff_col = diff_colour(light, *mat, light_dir, normal);
 				c3 spec_col = spec_colour(light, *mat, cam_dir, light_dir, normal);
@@ -981,8 +1160,9 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count, unsigned queue_capacity,
 		DevCounters *counters)
 {
-	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
-	int *stack = s_stack + threadIdx.x;
+	// one traversal stack per wave (packet traversal)
+	__shared__ int s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
+	int *stack = s_stack + (threadIdx.x >> 6) * RT_MAX_STACK;
 	unsigned long long local = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
 	unsigned long long sample = sample_first + local;
 	int px = 0, py = 0, k = 0;
@@ -1006,7 +1186,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	}
 	unsigned n_shadow = 0, n_env = 0;
 	c3 weight = { 1.0f, 1.0f, 1.0f };
-	c3 total = shade_vertex(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env);
+	c3 total = shade_vertex<true>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env);
 
 	// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
 	// not depend on the order in which lanes, waves or later bounces arrive.
@@ -1075,7 +1255,7 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 			slot = it.slot; key = it.key; depth = it.depth;
 			n_rays++;
 		}
-		c3 total = shade_vertex(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env);
+		c3 total = shade_vertex<false>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env);
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}
@@ -1139,7 +1319,7 @@ k_trace(DevScene sc, const double *rays, unsigned long long n, rtamd_hit_record 
 	r.surface = -1; r.triangle = -1; r.t = 0; r.pad = 0;
 	r.position[0] = r.position[1] = r.position[2] = 0;
 	r.normal[0] = r.normal[1] = r.normal[2] = 0;
-	if (trace<false>(sc, ray, stack, best)) {
+	if (trace<false, false>(sc, ray, stack, best)) {
 		d3 position, normal;
 		finish_hit(sc, ray, best, position, normal);
 		r.surface = best.surface;
