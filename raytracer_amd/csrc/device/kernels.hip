@@ -33,6 +33,8 @@ struct c3 { float r, g, b; };
 
 #define DEV __device__ __forceinline__
 
+DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // ---- vector.c ---------------------------------------------------------------
 DEV d3 vadd(d3 a, d3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }          // vector.c:11
 DEV d3 vsub(d3 a, d3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }          // vector.c:21
@@ -584,8 +586,9 @@ DEV PacketRay make_packet_ray(d3 o, d3 d)
 	return r;
 }
 
-DEV bool packet_box_test(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
-		float tlo, float thi, float &tn)
+// Widened [tn, tf] overlap of the ray with a box, clamped to [tlo, thi].
+DEV void packet_box_range(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+		float tlo, float thi, float &tn, float &tf)
 {
 	const float margin = 9.5367431640625e-7f;   // 2^-20
 	float ax = __builtin_fmaf(lox - r.ox, r.ix, r.cx), bx = __builtin_fmaf(hix - r.ox, r.ix, r.cx);
@@ -596,14 +599,61 @@ DEV bool packet_box_test(const PacketRay &r, float lox, float loy, float loz, fl
 	tnn = __builtin_fmaf(-__builtin_fabsf(tnn), margin, tnn - r.e);
 	tff = __builtin_fmaf(__builtin_fabsf(tff), margin, tff + r.e);
 	tn = __builtin_fmaxf(tnn, tlo);
-	float tf = __builtin_fminf(tff, thi);
-	return tn <= tf;
+	tf = __builtin_fminf(tff, thi);
+}
+
+typedef unsigned long long u64;
+
+// The triangle test of ray.c:327-358 for a packet: the cheap rejections are
+// evaluated by every lane and decided wave-wide, so the common case (no lane
+// can hit) costs no divergent branch; the exact quotients are computed only by
+// lanes that may hit.  `act` says whether this lane's ray takes part.
+DEV bool triangle_intersect_packet(d3 o, d3 d, const float4 &p0, const float4 &p1, const float4 &p2, bool act,
+		float &aa, float &bb, float &cc, double &t)
+{
+	d3 u = { (double)p0.x, (double)p0.y, (double)p0.z };
+	d3 v = { (double)p1.x, (double)p1.y, (double)p1.z };
+	d3 w = { (double)p2.x, (double)p2.y, (double)p2.z };
+	d3 edge1 = vsub(v, u);
+	d3 edge2 = vsub(w, u);
+	d3 pvec = vcross(d, edge2);
+	float det = (float)vdot(edge1, pvec);
+	d3 tvec = vsub(o, u);
+	const double x1 = vdot(tvec, pvec);
+	const float big = 3.0e38f;
+	const float rdet = __builtin_amdgcn_rcpf(det);
+	const float b_approx = (float)x1 * rdet;
+	bool maybe = act && !((b_approx < -1e-30f && b_approx > -big) || (b_approx > 1.0001f && b_approx < big));
+	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
+		return false;
+	d3 qvec = vcross(tvec, edge1);
+	const double x2 = vdot(d, qvec);
+	const float c_approx = (float)x2 * rdet;
+	const float s_approx = c_approx + b_approx;
+	maybe = maybe && !((c_approx < -1e-30f && c_approx > -big) ||
+			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big));
+	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
+		return false;
+	bool ok = false;
+	if (maybe) {
+		bb = (float)(x1 / (double)det);
+		if (!((double)bb < 0.0 || (double)bb > 1.0)) {
+			cc = (float)(x2 / (double)det);
+			if (!((double)cc < 0.0 || (double)(cc + bb) > 1.0)) {
+				aa = (float)(1.0 - (double)bb - (double)cc);
+				t = vdot(edge2, qvec) / (double)det;
+				ok = true;
+			}
+		}
+	}
+	return ok;
 }
 
 template <bool ANYHIT>
 DEV bool mesh_traverse_packet(const DevScene &sc, const DevMesh &mesh, d3 o, d3 d, float tnear, float tfar,
-		int *wstack, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
+		int *wstack_i, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
 {
+	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
 	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
 	const const_f4 tris = as_const(sc.tris + mesh.tri_first);
 	const PacketRay pr = make_packet_ray(o, d);
@@ -613,46 +663,51 @@ DEV bool mesh_traverse_packet(const DevScene &sc, const DevMesh &mesh, d3 o, d3 
 	best_orig = -1;
 	best_tri = -1;
 	float limit = tfar;
-	unsigned trail = 0;          // bit k: this lane's ray must visit stack entry k
-	int sp = 0;                  // wave-uniform
+	// wave-uniform state: the lanes whose ray must visit `ref`, the lanes that
+	// are finished (any-hit only), the stack depth
+	u64 actm = __builtin_amdgcn_ballot_w64(true);
+	u64 donem = 0;
+	int sp = 0;
 	int ref = __builtin_amdgcn_readfirstlane(mesh.root);
-	bool act = true;             // this lane's ray must visit `ref`
 	for (;;) {
-		if (ref >= 0) {
-			RT_STAT(if (lane_id() == 0) atomicAdd(&g_stat_nodes, 1ull));
+		bool at_leaf = true;
+		while (ref >= 0) {
+			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_nodes, 1ull));
 			const float4 q0 = cload(nodes, 4 * ref + 0), q1 = cload(nodes, 4 * ref + 1);
 			const float4 q2 = cload(nodes, 4 * ref + 2), q3 = cload(nodes, 4 * ref + 3);
-			float tn0, tn1;
-			bool h0 = packet_box_test(pr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0) && act;
-			bool h1 = packet_box_test(pr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1) && act;
-			const unsigned long long m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1);
+			float tn0, tf0, tn1, tf1;
+			packet_box_range(pr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0, tf0);
+			packet_box_range(pr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1, tf1);
+			const u64 m0 = __builtin_amdgcn_ballot_w64(tn0 <= tf0) & actm;
+			const u64 m1 = __builtin_amdgcn_ballot_w64(tn1 <= tf1) & actm;
 			const int c0 = as_i(q3.x), c1 = as_i(q3.y);
-			if (m0 != 0 && m1 != 0) {
-				bool swap = false;
-				if (!ANYHIT) {
-					// front-to-back for the majority of the lanes
-					unsigned long long want1 = __builtin_amdgcn_ballot_w64(h1 && (!h0 || tn1 < tn0));
-					unsigned long long want0 = __builtin_amdgcn_ballot_w64(h0 && (!h1 || tn0 <= tn1));
-					swap = __builtin_popcountll(want1) > __builtin_popcountll(want0);
-				}
-				const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-				const bool hn = swap ? h1 : h0, hf = swap ? h0 : h1;
-				wstack[sp] = farc;
-				trail = hf ? (trail | (1u << sp)) : (trail & ~(1u << sp));
-				sp++;
-				ref = nearc;
-				act = hn;
-				continue;
-			} else if (m0 != 0) {
-				ref = c0;
-				act = h0;
-				continue;
-			} else if (m1 != 0) {
-				ref = c1;
-				act = h1;
-				continue;
+			bool swap = false;
+			if (!ANYHIT) {
+				// front-to-back for the majority of the lanes
+				const u64 pref1 = __builtin_amdgcn_ballot_w64(tn1 < tn0);
+				const u64 both = m0 & m1;
+				const u64 w1 = (both & pref1) | (m1 & ~m0), w0 = (both & ~pref1) | (m0 & ~m1);
+				swap = __builtin_popcountll(w1) > __builtin_popcountll(w0);
 			}
-		} else {
+			u64 nm = swap ? m1 : m0, fm = swap ? m0 : m1;
+			int nc = swap ? c1 : c0, fc = swap ? c0 : c1;
+			if (nm == 0) {
+				nm = fm;
+				nc = fc;
+				fm = 0;
+			}
+			if (nm == 0) {
+				at_leaf = false;
+				break;
+			}
+			if (fm != 0) {
+				wstack[sp] = make_int4(fc, (int)(unsigned)fm, (int)(unsigned)(fm >> 32), 0);
+				sp++;
+			}
+			ref = nc;
+			actm = nm;
+		}
+		if (at_leaf) {
 			const int v = ~ref;
 			const int first = v >> 2, count = (v & 3) + 1;
 			for (int i = 0; i < count; i++) {
@@ -661,42 +716,46 @@ DEV bool mesh_traverse_packet(const DevScene &sc, const DevMesh &mesh, d3 o, d3 
 				const float4 p2 = cload(tris, 3 * (first + i) + 2);
 				float aa, bb, cc;
 				double t;
-				RT_STAT(if (lane_id() == 0) atomicAdd(&g_stat_tris, 1ull));
-				if (!act || !triangle_intersect(o, d, p0, p1, p2, aa, bb, cc, t))
-					continue;
+				RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
+				const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
+				const bool ok = triangle_intersect_packet(o, d, p0, p1, p2, act, aa, bb, cc, t);
 				int orig = as_i(p0.w);
-				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
+				if (ok && t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
 					best_t = t;
 					best_orig = orig;
 					best_tri = first + i;
 					ba = aa; bb_ = bb; bc = cc;
 					found = true;
-					if (ANYHIT) {
-						act = false;
-					} else {
+					if (!ANYHIT) {
+						// next float above or equal to t: boxes further than this cannot win
 						float ft = (float)t;
 						if ((double)ft < t)
 							ft = next_up(ft);
 						limit = ft < tfar ? ft : tfar;
 					}
 				}
+				if (ANYHIT) {
+					donem = __builtin_amdgcn_ballot_w64(found);
+					actm &= ~donem;
+					if (actm == 0)
+						break;
+				}
 			}
 		}
 		// next stack entry that some lane still has to visit
-		bool any = false;
-		while (sp > 0) {
+		for (;;) {
+			if (sp == 0)
+				return found;
 			sp--;
-			act = ((trail >> sp) & 1u) != 0 && !(ANYHIT && found);
-			if (__builtin_amdgcn_ballot_w64(act) != 0) {
-				ref = __builtin_amdgcn_readfirstlane(wstack[sp]);
-				any = true;
+			const int4 e = wstack[sp];
+			ref = __builtin_amdgcn_readfirstlane(e.x);
+			const u64 m = (u64)(unsigned)__builtin_amdgcn_readfirstlane(e.y) |
+					((u64)(unsigned)__builtin_amdgcn_readfirstlane(e.z) << 32);
+			actm = m & ~donem;
+			if (actm != 0)
 				break;
-			}
 		}
-		if (!any)
-			break;
 	}
-	return found;
 }
 
 // ---- ray.c:483-578 + 643-672 ---------------------------------------------------
@@ -874,7 +933,6 @@ DEV c3 spec_colour(const DevLight &light, const DevMaterial &mat, d3 first, d3 s
 
 // ---- wave helpers ------------------------------------------------------------
 
-DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Adds per-lane counts into a global counter with one atomic per wave.
 DEV void wave_count_add(unsigned long long *counter, unsigned value)
@@ -1161,8 +1219,8 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		DevCounters *counters)
 {
 	// one traversal stack per wave (packet traversal)
-	__shared__ int s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
-	int *stack = s_stack + (threadIdx.x >> 6) * RT_MAX_STACK;
+	__shared__ int4 s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
+	int *stack = reinterpret_cast<int *>(s_stack + (threadIdx.x >> 6) * RT_MAX_STACK);
 	unsigned long long local = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
 	unsigned long long sample = sample_first + local;
 	int px = 0, py = 0, k = 0;
