@@ -31,6 +31,19 @@ namespace {
 struct d3 { double x, y, z; };
 struct c3 { float r, g, b; };
 
+// Scene tables are read through the constant address space: a wave-uniform
+// index then becomes a scalar load (one fetch per wave through the scalar
+// cache) instead of 64 identical vector loads.
+#define CONSTAS __attribute__((address_space(4)))
+typedef const CONSTAS DevSurface CSurface;
+typedef const CONSTAS DevLight CLight;
+typedef const CONSTAS DevMaterial CMaterial;
+typedef const CONSTAS DevMesh CMesh;
+template <typename T> __device__ __forceinline__ const CONSTAS T *in_const(const T *p)
+{
+	return (const CONSTAS T *)(unsigned long long)p;
+}
+
 #define DEV __device__ __forceinline__
 
 DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -46,21 +59,21 @@ DEV d3 vcross(d3 a, d3 b)                                                       
 {
 	return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
 }
-DEV d3 ld3(const double *p) { return { p[0], p[1], p[2] }; }
+template <typename P> DEV d3 ld3(P p) { return { p[0], p[1], p[2] }; }
 
 // ---- colour.c ---------------------------------------------------------------
 DEV c3 cadd(c3 a, c3 b) { return { a.r + b.r, a.g + b.g, a.b + b.b }; }          // colour.c:8
 DEV c3 cmul(c3 a, c3 b) { return { a.r * b.r, a.g * b.g, a.b * b.b }; }          // colour.c:19
 DEV c3 cscale(float s, c3 a) { return { s * a.r, s * a.g, s * a.b }; }           // colour.c:30
-DEV c3 lc3(const float *p) { return { p[0], p[1], p[2] }; }
+template <typename P> DEV c3 lc3(P p) { return { p[0], p[1], p[2] }; }
 
 #define M4(m, i, j) (m)[4 * (j) + (i)]
 
 // matrix.c:61-81 + vector.c:95-104.  For an affine matrix the homogeneous
 // coordinate is exactly 1 and x / 1 == x, so the divide is skipped.
-DEV d3 xform_point(const DevSurface &s, d3 v)
+DEV d3 xform_point(CSurface &s, d3 v)
 {
-	const double *m = s.w2m;
+	const CONSTAS double *m = s.w2m;
 	const double v0 = v.x, v1 = v.y, v2 = v.z, v3 = 1.0;
 	double x = M4(m, 0, 0) * v0 + M4(m, 0, 1) * v1 + M4(m, 0, 2) * v2 + M4(m, 0, 3) * v3;
 	double y = M4(m, 1, 0) * v0 + M4(m, 1, 1) * v1 + M4(m, 1, 2) * v2 + M4(m, 1, 3) * v3;
@@ -72,7 +85,7 @@ DEV d3 xform_point(const DevSurface &s, d3 v)
 }
 
 // matrix.c:83-96
-DEV d3 xform_dir(const double *m, d3 v)
+DEV d3 xform_dir(const CONSTAS double *m, d3 v)
 {
 	const double v0 = v.x, v1 = v.y, v2 = v.z;
 	d3 out;
@@ -83,7 +96,7 @@ DEV d3 xform_dir(const double *m, d3 v)
 }
 
 // transpose(world_to_model) applied as a direction, ray.c:492-493,576
-DEV d3 xform_normal(const double *w, d3 n)
+DEV d3 xform_normal(const CONSTAS double *w, d3 n)
 {
 	const double n0 = n.x, n1 = n.y, n2 = n.z;
 	d3 out;
@@ -131,7 +144,7 @@ DEV double keyed_drand(uint32_t key, uint32_t purpose, uint32_t index)
 enum { PURPOSE_AA = 0, PURPOSE_LIGHT0 = 1, PURPOSE_GLOSSY = 16 };
 
 // ---- ray.c:580-641 ------------------------------------------------------------
-DEV bool surface_bbox_test(const float *bbox, const Ray &ray, float &bnear, float &bfar)
+DEV bool surface_bbox_test(const CONSTAS float *bbox, const Ray &ray, float &bnear, float &bfar)
 {
 	float xmin = bbox[0], xmax = bbox[3];
 	float ymin = bbox[1], ymax = bbox[4];
@@ -169,7 +182,7 @@ DEV bool surface_bbox_test(const float *bbox, const Ray &ray, float &bnear, floa
 // Each returns the number of candidates (ray.c:500-524) and fills ts/ncodes.
 
 // ray.c:69-97
-DEV int plane_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+DEV int plane_intersect(CSurface &s, d3 o, d3 d, float ts[2], int nc[2])
 {
 	d3 n = ld3(s.pn), axn = ld3(s.paxn), bxn = ld3(s.pbxn);
 	double ddn = vdot(d, n);
@@ -186,7 +199,7 @@ DEV int plane_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
 }
 
 // ray.c:99-120
-DEV int disk_intersect(const DevSurface &s, d3 o, d3 d, float tnear, float ts[2], int nc[2])
+DEV int disk_intersect(CSurface &s, d3 o, d3 d, float tnear, float ts[2], int nc[2])
 {
 	if (d.z == 0)
 		return 0;
@@ -202,7 +215,7 @@ DEV int disk_intersect(const DevSurface &s, d3 o, d3 d, float tnear, float ts[2]
 }
 
 // ray.c:122-151
-DEV int sphere_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+DEV int sphere_intersect(CSurface &s, d3 o, d3 d, float ts[2], int nc[2])
 {
 	float radius = s.radius;
 	float vv = (float)vdot(o, o);
@@ -224,7 +237,7 @@ DEV int sphere_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2]
 }
 
 // ray.c:153-271
-DEV int cylinder_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+DEV int cylinder_intersect(CSurface &s, d3 o, d3 d, float ts[2], int nc[2])
 {
 	const float height = s.height, radius = s.radius;
 	const bool capped = s.capped != 0;
@@ -270,7 +283,7 @@ DEV int cylinder_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[
 }
 
 // ray.c:273-324 (reports ONE candidate, ray.c:323)
-DEV int cone_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
+DEV int cone_intersect(CSurface &s, d3 o, d3 d, float ts[2], int nc[2])
 {
 	float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
 	float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
@@ -297,7 +310,7 @@ DEV int cone_intersect(const DevSurface &s, d3 o, d3 d, float ts[2], int nc[2])
 }
 
 // Model-space normal of an analytic primitive for the winning candidate.
-DEV d3 primitive_normal(const DevSurface &s, d3 o, d3 d, float t, int ncode)
+DEV d3 primitive_normal(CSurface &s, d3 o, d3 d, float t, int ncode)
 {
 	switch (ncode) {
 	case NC_POS_Z: return { 0, 0, 1 };
@@ -451,7 +464,7 @@ __device__ unsigned long long g_stat_nodes, g_stat_tris;
 #endif
 
 template <bool ANYHIT>
-DEV bool mesh_traverse(const DevScene &sc, const DevMesh &mesh, d3 o, d3 d, float tnear, float tfar,
+DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear, float tfar,
 		int *stack, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
 {
 	const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes + mesh.node_first);
@@ -650,7 +663,7 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, const float4 &p0, const float4 &p
 }
 
 template <bool ANYHIT>
-DEV bool mesh_traverse_packet(const DevScene &sc, const DevMesh &mesh, d3 o, d3 d, float tnear, float tfar,
+DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear, float tfar,
 		int *wstack_i, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
 {
 	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
@@ -767,7 +780,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 	best.tri = -1;
 	best.t = __builtin_huge_valf();
 	for (int si = 0; si < sc.num_surfaces; si++) {
-		const DevSurface &s = sc.surfaces[si];
+		CSurface &s = in_const(sc.surfaces)[si];
 		float bnear, bfar;
 		if (!surface_bbox_test(s.bbox, ray, bnear, bfar))
 			continue;
@@ -788,10 +801,10 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 			int orig;
 			double t;
 			if (PACKET)
-				hits = mesh_traverse_packet<ANYHIT>(sc, sc.meshes[s.mesh], o, d, bnear, bfar, stack,
+				hits = mesh_traverse_packet<ANYHIT>(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar, stack,
 						tri, orig, t, ba, bb, bc) ? 1 : 0;
 			else
-				hits = mesh_traverse<ANYHIT>(sc, sc.meshes[s.mesh], o, d, bnear, bfar, stack,
+				hits = mesh_traverse<ANYHIT>(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar, stack,
 						tri, orig, t, ba, bb, bc) ? 1 : 0;
 			ts[0] = (float)t;                       // ray.c:471
 			nc[0] = NC_MESH;
@@ -836,12 +849,12 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 // Position and world-space normal of the winning hit, ray.c:574-576.
 DEV void finish_hit(const DevScene &sc, const Ray &ray, const Best &best, d3 &position, d3 &normal)
 {
-	const DevSurface &s = sc.surfaces[best.surface];
+	CSurface &s = in_const(sc.surfaces)[best.surface];
 	position = vadd(ray.o, vscale((double)best.t, ray.d));
 	d3 n;
 	if (best.ncode == NC_MESH) {
 		// ray.c:472-475
-		const DevMesh &mesh = sc.meshes[s.mesh];
+		CMesh &mesh = in_const(sc.meshes)[s.mesh];
 		const float4 *nrm = reinterpret_cast<const float4 *>(sc.normals + mesh.tri_first) + 3 * best.tri;
 		const float4 a = nrm[0], b = nrm[1], c = nrm[2];
 		d3 n0 = { (double)a.x, (double)a.y, (double)a.z };
@@ -911,7 +924,7 @@ DEV c3 cubemap_colour(const DevScene &sc, d3 d)
 // ---- lighting.c ----------------------------------------------------------------
 
 // lighting.c:7-19
-DEV c3 diff_colour(const DevLight &light, const DevMaterial &mat, d3 light_dir, d3 normal)
+DEV c3 diff_colour(CLight &light, CMaterial &mat, d3 light_dir, d3 normal)
 {
 	double dp = vdot(light_dir, normal);
 	float ndotv = (float)(0 > dp ? 0.0 : dp);
@@ -921,7 +934,7 @@ DEV c3 diff_colour(const DevLight &light, const DevMaterial &mat, d3 light_dir, 
 
 // lighting.c:21-34 (called with cam_dir and light_dir swapped, shading.c:52; the
 // half vector is symmetric in them)
-DEV c3 spec_colour(const DevLight &light, const DevMaterial &mat, d3 first, d3 second, d3 normal)
+DEV c3 spec_colour(CLight &light, CMaterial &mat, d3 first, d3 second, d3 normal)
 {
 	d3 half = vnorm(vadd(first, second));
 	double dp = vdot(half, normal);
@@ -998,7 +1011,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 		r.surface = hit ? best.surface : -1;
 		r.triangle = -1;
 		if (hit && best.ncode == NC_MESH) {
-			const DevMesh &mesh = sc.meshes[sc.surfaces[best.surface].mesh];
+			CMesh &mesh = in_const(sc.meshes)[in_const(sc.surfaces)[best.surface].mesh];
 			r.triangle = as_i(reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first)[3 * best.tri].w);
 		}
 		r.t = hit ? best.t : 0.0f;
@@ -1009,7 +1022,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	}
 
 	int n_children = 0;
-	const DevMaterial *mat = nullptr;
+	CMaterial *mat = nullptr;
 	if (active && !hit) {
 		// shading.c:123-129
 		if (sc.has_cubemap) {
@@ -1018,11 +1031,11 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 		} else
 			total = lc3(sc.background);
 	} else if (active) {
-		mat = &sc.materials[sc.surfaces[best.surface].material];
+		mat = &in_const(sc.materials)[in_const(sc.surfaces)[best.surface].material];
 		d3 cam_dir = vnorm(vscale(-1, ray.d));                       // shading.c:118
 		// shading.c:133-135 -> hit_light_colour, shading.c:7-58
 		for (int li = 0; li < sc.num_lights; li++) {
-			const DevLight &light = sc.lights[li];
+			CLight &light = in_const(sc.lights)[li];
 			const bool area = light.type == RTAMD_LIGHT_AREA;
 			const int n = area ? sc.shadow_samples : 1;
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
@@ -1382,7 +1395,7 @@ k_trace(DevScene sc, const double *rays, unsigned long long n, rtamd_hit_record 
 		finish_hit(sc, ray, best, position, normal);
 		r.surface = best.surface;
 		if (best.ncode == NC_MESH) {
-			const DevMesh &mesh = sc.meshes[sc.surfaces[best.surface].mesh];
+			CMesh &mesh = in_const(sc.meshes)[in_const(sc.surfaces)[best.surface].mesh];
 			r.triangle = as_i(reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first)[3 * best.tri].w);
 		}
 		r.t = best.t;
