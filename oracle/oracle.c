@@ -436,7 +436,9 @@ static double drand_src(Ctx *c, uint32_t key, uint32_t purpose, uint32_t index)
 	c->st.draws++;
 	if (c->rng_mode == 0)
 		return glibc_rand(c->glibc) / ((double)2147483647);
-	return oracle_keyed_draw(key, purpose, index) / ((double)2147483647);
+	/* keyed sequence: scaled by the double nearest to 1/RAND_MAX (same definition
+	 * as the HIP kernels) */
+	return oracle_keyed_draw(key, purpose, index) * 4.6566128752457969e-10;
 }
 
 /* ------------------------------------------------------------ camera rays */

@@ -216,6 +216,16 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		s.height = bs[i].height;
 		std::memcpy(s.w2m, bs[i].world_to_model, sizeof s.w2m);
 		s.affine = s.w2m[3] == 0.0 && s.w2m[7] == 0.0 && s.w2m[11] == 0.0 && s.w2m[15] == 1.0;
+		{
+			bool ident = s.affine != 0;
+			for (int c = 0; c < 3 && ident; c++)
+				for (int r = 0; r < 3; r++) {
+					double e = s.w2m[4 * c + r];
+					if (r == c ? e != 1.0 : (e != 0.0 || std::signbit(e)))
+						ident = false;
+				}
+			s.linear_identity = ident;
+		}
 		if (s.shape_type == RTAMD_SHAPE_PLANE) {
 			// ray.c:76-82: n = a x b, axn = a x n, bxn = b x n, det = a . bxn
 			cross3(bs[i].edge1, bs[i].edge2, s.pn);
@@ -238,6 +248,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	std::vector<DevMesh> meshes(h.num_meshes);
 	std::vector<DevBvhNode> nodes;
 	std::vector<DevTriangle> tris, normals;
+	std::vector<DevTriEdges> edges;
 	for (int m = 0; m < h.num_meshes; m++) {
 		const rtamd_mesh &bmh = bmesh[m];
 		const double *v = reinterpret_cast<const double *>(base + bmh.off_vertex);
@@ -293,6 +304,17 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 			std::memcpy(&tp.v[3], &orig, 4);
 			tris.push_back(tp);
 			normals.push_back(tn);
+			DevTriEdges te;
+			std::memset(&te, 0, sizeof te);
+			for (int a = 0; a < 3; a++) {
+				// vec3_sub(v, u), vec3_sub(w, u): ray.c:334-335, vector.c:21-29
+				const double u = pos[9 * (size_t)orig + a];
+				te.u[a] = u;
+				te.e1[a] = (double)pos[9 * (size_t)orig + 3 + a] - u;
+				te.e2[a] = (double)pos[9 * (size_t)orig + 6 + a] - u;
+			}
+			te.orig = orig;
+			edges.push_back(te);
 		}
 	}
 	if (nodes.empty())
@@ -318,6 +340,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	if ((rc = upload(sc, nodes, &d.nodes))) return rc;
 	if ((rc = upload(sc, tris, &d.tris))) return rc;
 	if ((rc = upload(sc, normals, &d.normals))) return rc;
+	if ((rc = upload(sc, edges, &d.edges))) return rc;
 	if ((rc = upload(sc, texels, &d.texels))) return rc;
 
 	void *p = nullptr;

@@ -71,7 +71,32 @@ template <typename P> DEV c3 lc3(P p) { return { p[0], p[1], p[2] }; }
 
 // matrix.c:61-81 + vector.c:95-104.  For an affine matrix the homogeneous
 // coordinate is exactly 1 and x / 1 == x, so the divide is skipped.
+// world_to_model whose 3x3 part is exactly the identity (all zeros +0): the
+// products with 0 and 1 only matter for the sign of an exact zero, so
+//   point:     x' = x + T   unless x == 0 and T == 0
+//   direction: x' = x       unless x == 0
+// and those cases take the general formula.  Bit-identical to matrix.c:61-96.
+DEV d3 xform_point_general(CSurface &s, d3 v);
+DEV d3 xform_dir_general(const CONSTAS double *m, d3 v);
+
 DEV d3 xform_point(CSurface &s, d3 v)
+{
+	if (s.linear_identity) {
+		const double tx = s.w2m[12], ty = s.w2m[13], tz = s.w2m[14];
+		if (!((v.x == 0 && tx == 0) || (v.y == 0 && ty == 0) || (v.z == 0 && tz == 0)))
+			return { v.x + tx, v.y + ty, v.z + tz };
+	}
+	return xform_point_general(s, v);
+}
+
+DEV d3 xform_dir(CSurface &s, d3 v)
+{
+	if (s.linear_identity && v.x != 0 && v.y != 0 && v.z != 0)
+		return v;
+	return xform_dir_general(s.w2m, v);
+}
+
+DEV d3 xform_point_general(CSurface &s, d3 v)
 {
 	const CONSTAS double *m = s.w2m;
 	const double v0 = v.x, v1 = v.y, v2 = v.z, v3 = 1.0;
@@ -85,7 +110,7 @@ DEV d3 xform_point(CSurface &s, d3 v)
 }
 
 // matrix.c:83-96
-DEV d3 xform_dir(const CONSTAS double *m, d3 v)
+DEV d3 xform_dir_general(const CONSTAS double *m, d3 v)
 {
 	const double v0 = v.x, v1 = v.y, v2 = v.z;
 	d3 out;
@@ -136,10 +161,13 @@ DEV uint32_t hash2(uint32_t a, uint32_t b)
 }
 DEV uint32_t key0_of(uint32_t seed, uint32_t pixel, uint32_t sample) { return hash2(hash2(seed, pixel), sample); }
 DEV uint32_t key_child(uint32_t key, uint32_t child) { return hash2(key ^ 0xa511e9b3u, child + 1u); }
-// drand() = rand() / (double) RAND_MAX, ray.c:14-17
+// The keyed stand-in for drand() (ray.c:14-17): a 31-bit value scaled into [0, 1]
+// by the double nearest to 1/RAND_MAX (a product, not a quotient: this sequence
+// is this implementation's own and the CPU checker defines it the same way).
+#define KEYED_SCALE 4.6566128752457969e-10
 DEV double keyed_drand(uint32_t key, uint32_t purpose, uint32_t index)
 {
-	return (double)(hash2(hash2(key, purpose), index) >> 1) / ((double)2147483647);
+	return (double)(hash2(hash2(key, purpose), index) >> 1) * KEYED_SCALE;
 }
 enum { PURPOSE_AA = 0, PURPOSE_LIGHT0 = 1, PURPOSE_GLOSSY = 16 };
 
@@ -621,14 +649,9 @@ typedef unsigned long long u64;
 // evaluated by every lane and decided wave-wide, so the common case (no lane
 // can hit) costs no divergent branch; the exact quotients are computed only by
 // lanes that may hit.  `act` says whether this lane's ray takes part.
-DEV bool triangle_intersect_packet(d3 o, d3 d, const float4 &p0, const float4 &p1, const float4 &p2, bool act,
+DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool act,
 		float &aa, float &bb, float &cc, double &t)
 {
-	d3 u = { (double)p0.x, (double)p0.y, (double)p0.z };
-	d3 v = { (double)p1.x, (double)p1.y, (double)p1.z };
-	d3 w = { (double)p2.x, (double)p2.y, (double)p2.z };
-	d3 edge1 = vsub(v, u);
-	d3 edge2 = vsub(w, u);
 	d3 pvec = vcross(d, edge2);
 	float det = (float)vdot(edge1, pvec);
 	d3 tvec = vsub(o, u);
@@ -668,7 +691,7 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 {
 	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
 	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
-	const const_f4 tris = as_const(sc.tris + mesh.tri_first);
+	const CONSTAS DevTriEdges *edges = in_const(sc.edges) + mesh.tri_first;
 	const PacketRay pr = make_packet_ray(o, d);
 	const double dnear = (double)tnear, dfar = (double)tfar;
 	bool found = false;
@@ -724,15 +747,13 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 			const int v = ~ref;
 			const int first = v >> 2, count = (v & 3) + 1;
 			for (int i = 0; i < count; i++) {
-				const float4 p0 = cload(tris, 3 * (first + i) + 0);
-				const float4 p1 = cload(tris, 3 * (first + i) + 1);
-				const float4 p2 = cload(tris, 3 * (first + i) + 2);
+				const CONSTAS DevTriEdges &te = edges[first + i];
 				float aa, bb, cc;
 				double t;
 				RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
 				const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
-				const bool ok = triangle_intersect_packet(o, d, p0, p1, p2, act, aa, bb, cc, t);
-				int orig = as_i(p0.w);
+				const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, aa, bb, cc, t);
+				int orig = te.orig;
 				if (ok && t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
 					best_t = t;
 					best_orig = orig;
@@ -785,7 +806,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 		if (!surface_bbox_test(s.bbox, ray, bnear, bfar))
 			continue;
 		d3 o = xform_point(s, ray.o);
-		d3 d = xform_dir(s.w2m, ray.d);
+		d3 d = xform_dir(s, ray.d);
 		float ts[2] = { -__builtin_huge_valf(), -__builtin_huge_valf() };
 		int nc[2] = { NC_FROM_T, NC_FROM_T };
 		int hits;
@@ -863,7 +884,7 @@ DEV void finish_hit(const DevScene &sc, const Ray &ray, const Best &best, d3 &po
 		n = vadd(vadd(vscale((double)best.a, n0), vscale((double)best.b, n1)), vscale((double)best.c, n2));
 	} else {
 		d3 o = xform_point(s, ray.o);
-		d3 d = xform_dir(s.w2m, ray.d);
+		d3 d = xform_dir(s, ray.d);
 		n = primitive_normal(s, o, d, best.t, best.ncode);
 	}
 	normal = vnorm(xform_normal(s.w2m, n));

@@ -20,7 +20,7 @@ struct DevSurface {
 	int32_t mesh;
 	int32_t capped;
 	int32_t affine;            /* world_to_model row 3 is exactly (0,0,0,1) */
-	int32_t pad0;
+	int32_t linear_identity;   /* affine and the 3x3 part is exactly I (zeros +0) */
 	float radius, height;
 	double w2m[16];            /* column-major, matrix.c:66 */
 	/* plane (ray.c:69-97): n = e1 x e2, axn = e1 x n, bxn = e2 x n, det = e1 . bxn */
@@ -65,6 +65,18 @@ struct DevTriangle {
 	float v[12];
 };
 
+/* Leaf-ordered triangle for the packet traversal: first vertex and the two edge
+ * vectors of ray.c:334-335 (edge = v - u evaluated in double on the host, the
+ * same single rounding the reference performs per ray), plus the triangle's
+ * index in the mesh's own array.  80 bytes, fetched with scalar loads. */
+struct DevTriEdges {
+	double u[3];
+	double e1[3];
+	double e2[3];
+	int32_t orig;
+	int32_t pad[1];
+};
+
 struct DevMesh {
 	int32_t node_first;        /* into nodes[] */
 	int32_t tri_first;         /* into tris[] / normals[] */
@@ -99,6 +111,7 @@ struct DevScene {
 	const DevBvhNode *nodes;
 	const DevTriangle *tris;
 	const DevTriangle *normals; /* same order as tris: n0, n1, n2 */
+	const DevTriEdges *edges;   /* same order as tris */
 	const float *texels;        /* float4 RGBA */
 	DevCubeFace faces[6];
 };
