@@ -428,6 +428,8 @@ typedef struct Ctx {
 	int rng_mode;
 	Glibc *glibc;
 	oracle_stats st;
+	double *ray_log;          /* optional: 8 doubles per ray_intersect call */
+	size_t ray_log_cap, ray_log_n;
 } Ctx;
 
 /* drand (ray.c:14-17): rand()/RAND_MAX, or the keyed equivalent. */
@@ -851,6 +853,12 @@ static int ray_bbox_test(Ray ray, const float *bbox, Ray *bray)
 static int ray_intersect(Ctx *c, Ray ray, Hit *hit)
 {
 	Hit test_hit;
+	if (c->ray_log && c->ray_log_n < c->ray_log_cap) {
+		double *o = c->ray_log + 8 * c->ray_log_n++;
+		o[0] = ray.origin.x; o[1] = ray.origin.y; o[2] = ray.origin.z;
+		o[3] = ray.direction.x; o[4] = ray.direction.y; o[5] = ray.direction.z;
+		o[6] = ray.near; o[7] = ray.far;
+	}
 	hit->surface = -1;
 	hit->triangle = -1;
 	hit->t = HUGE_VAL;
@@ -1316,4 +1324,30 @@ int oracle_mesh_bruteforce(const oracle_scene *s, int m, const double *ray, doub
 	if (t_out)
 		*t_out = th.t;
 	return th.triangle;
+}
+
+/* Debugging aid: renders one pixel in serial-stream mode (draws of the pixels
+ * before it are skipped, so the scene must have fixed consumption) and logs
+ * every ray handed to ray_intersect.  Returns the number of rays logged. */
+size_t oracle_debug_pixel_rays(const oracle_scene *s, uint32_t seed, int x, int y, double *rays,
+		size_t cap, float *colour_out)
+{
+	const rtamd_blob_header *h = s->h;
+	const int spp = h->antialiasing ? SQUARE(h->aa_samples) : 1;
+	Glibc g;
+	Ctx ctx;
+	memset(&ctx, 0, sizeof ctx);
+	ctx.s = s;
+	ctx.glibc = &g;
+	glibc_seed(&g, seed);
+	if (h->antialiasing)
+		for (long long d = 0; d < 2LL * spp * ((long long)h->width * y + x); d++)
+			glibc_rand(&g);
+	ctx.ray_log = rays;
+	ctx.ray_log_cap = cap;
+	float out[4];
+	pixel_colour(&ctx, x, y, seed, out, NULL);
+	if (colour_out)
+		memcpy(colour_out, out, sizeof out);
+	return ctx.ray_log_n;
 }

@@ -73,6 +73,11 @@ int oracle_camera_rays(const oracle_scene *s, const int32_t *pixels, const float
  * used to check the BVH traversal.  ray = double[8]. Returns triangle or -1. */
 int oracle_mesh_bruteforce(const oracle_scene *s, int m, const double *ray, double *t_out);
 
+/* Debugging aid: one pixel in serial-stream mode with every ray_intersect call
+ * logged (8 doubles per ray); returns the number of rays. */
+size_t oracle_debug_pixel_rays(const oracle_scene *s, uint32_t seed, int x, int y, double *rays,
+		size_t cap, float *colour_out);
+
 /* The keyed generator, exposed so tests can pin its definition. */
 uint32_t oracle_keyed_key0(uint32_t seed, uint32_t pixel, uint32_t sample);
 uint32_t oracle_keyed_child(uint32_t key, uint32_t child);

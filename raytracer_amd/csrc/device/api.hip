@@ -542,7 +542,11 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		HIP_TRY(hipEventCreate(&ev[1]));
 		HIP_TRY(hipEventRecord(ev[0], stream));
 	}
-	HIP_TRY(hipMemsetAsync(sc->d_accum, 0, pixels * 3 * sizeof(long long), stream));
+	// Without reflections, and with all samples of a pixel inside one wave, the
+	// primary kernel writes finished pixels itself: no accumulators, no resolve.
+	const bool direct = !dev.any_reflective && 64 % dev.spp == 0;
+	if (!direct)
+		HIP_TRY(hipMemsetAsync(sc->d_accum, 0, pixels * 3 * sizeof(long long), stream));
 	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DevCounters), stream));
 
 	int launches_primary = 0, launches_bounce = 0;
@@ -565,7 +569,7 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			HIP_TRY(hipEventRecord(a, stream));
 		}
 		HIP_TRY(rt_launch_primary(dev, p, first, count, sc->d_glibc, sc->d_accum,
-				static_cast<rtamd_hit_record *>(d_hits), levels ? sc->d_queue[0] : nullptr,
+				direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits), levels ? sc->d_queue[0] : nullptr,
 				levels ? sc->d_qcount : nullptr, sc->queue_capacity, sc->d_counters, stream));
 		if (stats && pev.size() <= 4096 && !pev.empty())
 			HIP_TRY(hipEventRecord(pev.back(), stream));
@@ -578,8 +582,9 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			launches_bounce++;
 		}
 	}
-	HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), sc->d_counters,
-			stream));
+	if (!direct)
+		HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), sc->d_counters,
+				stream));
 
 	if (stats) {
 		std::memset(stats, 0, sizeof *stats);

@@ -10,8 +10,8 @@ unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_par
 
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
-		long long *accum, rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count,
-		unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
+		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
+		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
 hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
 		DevCounters *counters, unsigned grid_blocks, hipStream_t stream);

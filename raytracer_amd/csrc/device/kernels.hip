@@ -1241,14 +1241,19 @@ DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_t
 
 // Primary samples: camera ray, nearest hit, direct lighting with shadow rays,
 // environment lookup; children go to the bounce queue.  raytracer.c:32-54,78-84.
-// Four waves per SIMD (<= 128 VGPRs): measured 11 % faster than the 154-register
-// allocation the compiler picks on its own; five (<= 96) spills too much.
+// Register budget: the primary kernel is fastest at five waves per SIMD (<= 96
+// VGPRs, some spilling; measured 78.9 ms vs 83.9 ms at four and 81.5 ms at six
+// on the 1080p showcase frame); the bounce kernel keeps per-lane stacks in LDS
+// (32 KB per workgroup) and runs at four.
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4
+#define RT_MIN_WAVES 5
+#endif
+#ifndef RT_MIN_WAVES_BOUNCE
+#define RT_MIN_WAVES_BOUNCE 4
 #endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES)
 k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
-		int rng_mode, uint32_t seed, const int32_t *glibc_table, long long *accum,
+		int rng_mode, uint32_t seed, const int32_t *glibc_table, long long *accum, float *direct_out,
 		rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count, unsigned queue_capacity,
 		DevCounters *counters)
 {
@@ -1280,29 +1285,55 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	c3 weight = { 1.0f, 1.0f, 1.0f };
 	c3 total = shade_vertex<true>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env);
 
-	// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
-	// not depend on the order in which lanes, waves or later bounces arrive.
-	long long r = active ? to_fixed(total.r) : 0, g = active ? to_fixed(total.g) : 0,
-	     b = active ? to_fixed(total.b) : 0;
 	const unsigned lane = lane_id();
-	// segmented reduction over runs of lanes that share a pixel (runs are contiguous)
-	uint32_t seg = active ? slot : 0xffffffffu;
-	for (int off = 1; off < 64; off <<= 1) {
-		uint32_t oseg = __shfl_down(seg, off, 64);
-		long long orr = __shfl_down(r, off, 64), og = __shfl_down(g, off, 64), ob = __shfl_down(b, off, 64);
-		// lane + off belongs to my run only if every lane in between does, which holds
-		// for contiguous runs when its slot equals mine
-		if (lane + off < 64 && oseg == seg) {
-			r += orr; g += og; b += ob;
+	if (64 % sc.spp == 0) {
+		// All samples of a pixel sit in consecutive lanes of this wave: add them in
+		// the reference's order, ((c0 + c1) + c2) + ... in float (raytracer.c:41-45).
+		const unsigned spp = (unsigned)sc.spp;
+		const unsigned base = lane - lane % spp;
+		float ar = total.r, ag = total.g, ab = total.b;
+		for (unsigned j = 1; j < spp; j++) {
+			ar += __shfl(total.r, (int)(base + j), 64);
+			ag += __shfl(total.g, (int)(base + j), 64);
+			ab += __shfl(total.b, (int)(base + j), 64);
 		}
-	}
-	uint32_t prev = __shfl_up(seg, 1, 64);
-	bool head = active && (lane == 0 || prev != seg);
-	if (head) {
-		unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
-		if (r) atomicAdd(p + 0, (unsigned long long)r);
-		if (g) atomicAdd(p + 1, (unsigned long long)g);
-		if (b) atomicAdd(p + 2, (unsigned long long)b);
+		if (active && lane == base) {
+			if (direct_out) {
+				// no other contribution can arrive: write the pixel (raytracer.c:46,81)
+				if (sc.antialiasing) {
+					const float s = (float)(1.0 / (double)sc.spp);
+					ar = s * ar; ag = s * ag; ab = s * ab;
+				}
+				float4 out = { ar, ag, ab, 0.0f };
+				reinterpret_cast<float4 *>(direct_out)[(unsigned long long)sc.width * py + px] = out;
+			} else {
+				accumulate(accum, slot, { ar, ag, ab });
+			}
+		}
+	} else {
+		// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
+		// not depend on the order in which lanes, waves or later bounces arrive.
+		long long r = active ? to_fixed(total.r) : 0, g = active ? to_fixed(total.g) : 0,
+		     b = active ? to_fixed(total.b) : 0;
+		// segmented reduction over runs of lanes that share a pixel (runs are contiguous)
+		uint32_t seg = active ? slot : 0xffffffffu;
+		for (int off = 1; off < 64; off <<= 1) {
+			uint32_t oseg = __shfl_down(seg, off, 64);
+			long long orr = __shfl_down(r, off, 64), og = __shfl_down(g, off, 64), ob = __shfl_down(b, off, 64);
+			// lane + off belongs to my run only if every lane in between does, which holds
+			// for contiguous runs when its slot equals mine
+			if (lane + off < 64 && oseg == seg) {
+				r += orr; g += og; b += ob;
+			}
+		}
+		uint32_t prev = __shfl_up(seg, 1, 64);
+		bool head = active && (lane == 0 || prev != seg);
+		if (head) {
+			unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
+			if (r) atomicAdd(p + 0, (unsigned long long)r);
+			if (g) atomicAdd(p + 1, (unsigned long long)g);
+			if (b) atomicAdd(p + 2, (unsigned long long)b);
+		}
 	}
 	wave_count_add(&counters->rays_primary, active ? 1u : 0u);
 	wave_count_add(&counters->rays_shadow, n_shadow);
@@ -1313,7 +1344,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 // (shading.c:114-141 at depth >= 1) and its radiance, scaled by the path
 // weight, is added to its pixel.  Grid-stride over the queue population, which
 // is read from device memory so the host never waits between bounces.
-__global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
 k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count, unsigned queue_capacity,
 		long long *accum, QueueItem *queue_out, unsigned *queue_out_count, DevCounters *counters)
 {
@@ -1504,15 +1535,15 @@ unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_par
 
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
-		long long *accum, rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count,
-		unsigned queue_capacity, DevCounters *counters, hipStream_t stream)
+		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
+		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream)
 {
 	if (!sample_count)
 		return hipSuccess;
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long blocks = (sample_count + RT_BLOCK - 1) / RT_BLOCK;
 	hipLaunchKernelGGL(k_primary, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm, sample_first,
-			sample_count, p.rng_mode, p.seed, glibc_table, accum, hits, queue_out, queue_count,
+			sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out, queue_count,
 			queue_capacity, counters);
 	return hipGetLastError();
 }
