@@ -582,6 +582,7 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			launches_bounce++;
 		}
 	}
+	HIP_TRY(rt_launch_collect_stats(sc->d_counters, stream));
 	if (!direct)
 		HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), sc->d_counters,
 				stream));

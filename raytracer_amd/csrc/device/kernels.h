@@ -18,6 +18,7 @@ hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
 		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
 		hipStream_t stream);
+hipError_t rt_launch_collect_stats(DevCounters *counters, hipStream_t stream);
 hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
 		rtamd_hit_record *hits, hipStream_t stream);
 hipError_t rt_launch_camera_rays(const DevScene &sc, const rtamd_render_params &p,

@@ -48,6 +48,41 @@ template <typename T> __device__ __forceinline__ const CONSTAS T *in_const(const
 
 DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Build option RT_TIMING=1|2: per-wave cycle counts per code region (1: the
+// stages of a sample, 2: also the inside of trace()), summed over the launch
+// and printed by k_collect_stats.  The counter reads perturb what they measure
+// (more so at level 2); the shares are a guide, not a measurement of the
+// uninstrumented kernel.
+#ifdef RT_TIMING
+enum { TM_KERNEL, TM_SETUP, TM_TRACE_PRIMARY, TM_FINISH, TM_LIGHT_SETUP, TM_TRACE_SHADOW, TM_SHADE, TM_ENV,
+	TM_SPAWN, TM_TAIL,
+	TM_IN_BBOX, TM_IN_XFORM, TM_IN_PRIM, TM_IN_MESH_SETUP, TM_IN_NODES, TM_IN_LEAVES, TM_IN_POP, TM_IN_SELECT,
+	TM_SHADOW_OFFSET = 8, TM_COUNT = TM_IN_SELECT + 1 + TM_SHADOW_OFFSET };
+__device__ unsigned long long g_timing[TM_COUNT];
+__shared__ unsigned long long s_timing[RT_BLOCK / 64][TM_COUNT];
+DEV unsigned long long tm_now() { return __builtin_readcyclecounter(); }
+DEV void tm_add(int cat, unsigned long long t0)
+{
+	const unsigned long long dt = tm_now() - t0;
+	if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+		atomicAdd(&s_timing[threadIdx.x >> 6][cat], dt);
+}
+#define TM_BEGIN(v) const unsigned long long v = tm_now()
+#define TM_END(cat, v) tm_add(cat, v)
+#if RT_TIMING >= 2
+#define TM2_BEGIN(v) TM_BEGIN(v)
+#define TM2_END(cat, v) tm_add((cat) + (ANYHIT ? TM_SHADOW_OFFSET : 0), v)
+#else
+#define TM2_BEGIN(v)
+#define TM2_END(cat, v)
+#endif
+#else
+#define TM_BEGIN(v)
+#define TM_END(cat, v)
+#define TM2_BEGIN(v)
+#define TM2_END(cat, v)
+#endif
+
 // ---- vector.c ---------------------------------------------------------------
 DEV d3 vadd(d3 a, d3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }          // vector.c:11
 DEV d3 vsub(d3 a, d3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }          // vector.c:21
@@ -596,51 +631,51 @@ DEV float4 cload(const_f4 p, int i)
 	return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// Float ray for the packet box tests: rounded origin `of`, reciprocal direction,
-// and c = -(o - of)/d, which puts the part of the origin lost in the rounding
-// back into each slab distance: t = (plane - of) * i + c.  What remains is
-// rounding of the operations themselves, covered by a relative margin on the
-// entry/exit distances plus the absolute term e.
+// Float ray for the packet box tests.  A slab distance (plane - o) / d is
+// evaluated as fma(plane, i, k) with i = 1/d and k = -o * i, both rounded to
+// float.  Against the exact distance T the result is off by at most
+// |T| * 2^-22 + |o * i| * 2^-23 (rounding of d, of 1/d, of k and of the fma), so
+// for distances inside a window [tlo, thi] the error is below
+//   E = max(|tlo|, |thi|) * 2^-20 + max|k| * 2^-22,
+// and a box whose true overlap with the window is not empty always satisfies
+//   max(entry, tlo) <= min(exit, thi) + 2E     (`slack` = 2E).
 struct PacketRay {
-	float ox, oy, oz;
 	float ix, iy, iz;
-	float cx, cy, cz;
-	float e;
+	float kx, ky, kz;
+	float slack;
 };
 
-DEV PacketRay make_packet_ray(d3 o, d3 d)
+DEV PacketRay make_packet_ray(d3 o, d3 d, float tlo, float thi)
 {
 	PacketRay r;
 	float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
+	// a zero component would turn plane * inf + k into NaN
 	if (__builtin_fabsf(fx) < 1e-30f) fx = __builtin_copysignf(1e-30f, fx);
 	if (__builtin_fabsf(fy) < 1e-30f) fy = __builtin_copysignf(1e-30f, fy);
 	if (__builtin_fabsf(fz) < 1e-30f) fz = __builtin_copysignf(1e-30f, fz);
 	r.ix = 1.0f / fx; r.iy = 1.0f / fy; r.iz = 1.0f / fz;
-	r.ox = (float)o.x; r.oy = (float)o.y; r.oz = (float)o.z;
-	float rx = (float)(o.x - (double)r.ox), ry = (float)(o.y - (double)r.oy), rz = (float)(o.z - (double)r.oz);
-	r.cx = -rx * r.ix; r.cy = -ry * r.iy; r.cz = -rz * r.iz;
-	// 2^-40 of the largest |o * (1/d)|: the absolute error left in a slab distance
-	// when (plane - of) * i and c cancel
-	float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.ox * r.ix), __builtin_fabsf(r.oy * r.iy)),
-			__builtin_fabsf(r.oz * r.iz));
-	r.e = m * 9.094947e-13f;
+	r.kx = (float)(-(o.x * (double)r.ix));
+	r.ky = (float)(-(o.y * (double)r.iy));
+	r.kz = (float)(-(o.z * (double)r.iz));
+	const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.kx), __builtin_fabsf(r.ky)), __builtin_fabsf(r.kz));
+	const float w = __builtin_fmaxf(__builtin_fabsf(tlo), __builtin_fabsf(thi));
+	r.slack = 2.0f * (w * 9.5367431640625e-7f + m * 2.384185791015625e-7f);
 	return r;
 }
 
-// Widened [tn, tf] overlap of the ray with a box, clamped to [tlo, thi].
-DEV void packet_box_range(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
-		float tlo, float thi, float &tn, float &tf)
+// Conservative overlap test of the ray with a box inside [tlo, thi]; tn is the
+// (unwidened) entry distance, used only to order the children.
+DEV bool packet_box_hit(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+		float tlo, float thi, float &tn)
 {
-	const float margin = 9.5367431640625e-7f;   // 2^-20
-	float ax = __builtin_fmaf(lox - r.ox, r.ix, r.cx), bx = __builtin_fmaf(hix - r.ox, r.ix, r.cx);
-	float ay = __builtin_fmaf(loy - r.oy, r.iy, r.cy), by = __builtin_fmaf(hiy - r.oy, r.iy, r.cy);
-	float az = __builtin_fmaf(loz - r.oz, r.iz, r.cz), bz = __builtin_fmaf(hiz - r.oz, r.iz, r.cz);
-	float tnn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-	float tff = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-	tnn = __builtin_fmaf(-__builtin_fabsf(tnn), margin, tnn - r.e);
-	tff = __builtin_fmaf(__builtin_fabsf(tff), margin, tff + r.e);
-	tn = __builtin_fmaxf(tnn, tlo);
-	tf = __builtin_fminf(tff, thi);
+	float ax = __builtin_fmaf(lox, r.ix, r.kx), bx = __builtin_fmaf(hix, r.ix, r.kx);
+	float ay = __builtin_fmaf(loy, r.iy, r.ky), by = __builtin_fmaf(hiy, r.iy, r.ky);
+	float az = __builtin_fmaf(loz, r.iz, r.kz), bz = __builtin_fmaf(hiz, r.iz, r.kz);
+	tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+			__builtin_fminf(az, bz)), tlo);
+	float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+			__builtin_fmaxf(az, bz)), thi);
+	return tn <= tf + r.slack;
 }
 
 typedef unsigned long long u64;
@@ -689,10 +724,11 @@ template <bool ANYHIT>
 DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear, float tfar,
 		int *wstack_i, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
 {
+	TM2_BEGIN(t_setup);
 	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
 	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
 	const CONSTAS DevTriEdges *edges = in_const(sc.edges) + mesh.tri_first;
-	const PacketRay pr = make_packet_ray(o, d);
+	const PacketRay pr = make_packet_ray(o, d, tnear, tfar);
 	const double dnear = (double)tnear, dfar = (double)tfar;
 	bool found = false;
 	best_t = __builtin_huge_val();
@@ -705,17 +741,19 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 	u64 donem = 0;
 	int sp = 0;
 	int ref = __builtin_amdgcn_readfirstlane(mesh.root);
+	TM2_END(TM_IN_MESH_SETUP, t_setup);
 	for (;;) {
 		bool at_leaf = true;
+		TM2_BEGIN(t_nodes);
 		while (ref >= 0) {
 			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_nodes, 1ull));
 			const float4 q0 = cload(nodes, 4 * ref + 0), q1 = cload(nodes, 4 * ref + 1);
 			const float4 q2 = cload(nodes, 4 * ref + 2), q3 = cload(nodes, 4 * ref + 3);
-			float tn0, tf0, tn1, tf1;
-			packet_box_range(pr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0, tf0);
-			packet_box_range(pr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1, tf1);
-			const u64 m0 = __builtin_amdgcn_ballot_w64(tn0 <= tf0) & actm;
-			const u64 m1 = __builtin_amdgcn_ballot_w64(tn1 <= tf1) & actm;
+			float tn0, tn1;
+			const bool h0 = packet_box_hit(pr, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0);
+			const bool h1 = packet_box_hit(pr, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1);
+			const u64 m0 = __builtin_amdgcn_ballot_w64(h0) & actm;
+			const u64 m1 = __builtin_amdgcn_ballot_w64(h1) & actm;
 			const int c0 = as_i(q3.x), c1 = as_i(q3.y);
 			bool swap = false;
 			if (!ANYHIT) {
@@ -743,6 +781,8 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 			ref = nc;
 			actm = nm;
 		}
+		TM2_END(TM_IN_NODES, t_nodes);
+		TM2_BEGIN(t_leaves);
 		if (at_leaf) {
 			const int v = ~ref;
 			const int first = v >> 2, count = (v & 3) + 1;
@@ -776,10 +816,14 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 				}
 			}
 		}
+		TM2_END(TM_IN_LEAVES, t_leaves);
 		// next stack entry that some lane still has to visit
+		TM2_BEGIN(t_pop);
 		for (;;) {
-			if (sp == 0)
+			if (sp == 0) {
+				TM2_END(TM_IN_POP, t_pop);
 				return found;
+			}
 			sp--;
 			const int4 e = wstack[sp];
 			ref = __builtin_amdgcn_readfirstlane(e.x);
@@ -789,6 +833,7 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 			if (actm != 0)
 				break;
 		}
+		TM2_END(TM_IN_POP, t_pop);
 	}
 }
 
@@ -803,10 +848,16 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 	for (int si = 0; si < sc.num_surfaces; si++) {
 		CSurface &s = in_const(sc.surfaces)[si];
 		float bnear, bfar;
-		if (!surface_bbox_test(s.bbox, ray, bnear, bfar))
+		TM2_BEGIN(t_bbox);
+		const bool in_box = surface_bbox_test(s.bbox, ray, bnear, bfar);
+		TM2_END(TM_IN_BBOX, t_bbox);
+		if (!in_box)
 			continue;
+		TM2_BEGIN(t_xform);
 		d3 o = xform_point(s, ray.o);
 		d3 d = xform_dir(s, ray.d);
+		TM2_END(TM_IN_XFORM, t_xform);
+		TM2_BEGIN(t_prim);
 		float ts[2] = { -__builtin_huge_valf(), -__builtin_huge_valf() };
 		int nc[2] = { NC_FROM_T, NC_FROM_T };
 		int hits;
@@ -832,8 +883,10 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 			break;
 		}
 		}
+		TM2_END(TM_IN_PRIM, t_prim);
 		if (hits == 0)
 			continue;
+		TM2_BEGIN(t_select);
 		float t;
 		int ncode;
 		if (hits == 1) {                             // ray.c:530-536
@@ -863,6 +916,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 			best.tri = tri;
 			best.a = ba; best.b = bb; best.c = bc;
 		}
+		TM2_END(TM_IN_SELECT, t_select);
 	}
 	return best.surface >= 0;
 }
@@ -1023,9 +1077,13 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	bool hit = false;
 	d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
 	if (active) {
+		TM_BEGIN(t_trace);
 		hit = trace<false, PACKET>(sc, ray, stack, best);
+		TM_END(TM_TRACE_PRIMARY, t_trace);
+		TM_BEGIN(t_finish);
 		if (hit)
 			finish_hit(sc, ray, best, position, normal);
+		TM_END(TM_FINISH, t_finish);
 	}
 	if (rec && active) {
 		rtamd_hit_record r;
@@ -1047,7 +1105,9 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	if (active && !hit) {
 		// shading.c:123-129
 		if (sc.has_cubemap) {
+			TM_BEGIN(t_env);
 			total = cubemap_colour(sc, ray.d);
+			TM_END(TM_ENV, t_env);
 			n_env++;
 		} else
 			total = lc3(sc.background);
@@ -1062,6 +1122,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
 			d3 lpos = ld3(light.position);
 			for (int j = 0; j < n * n; j++) {
+				TM_BEGIN(t_lsetup);
 				d3 light_pos = lpos;
 				if (area) {
 					int p = j % n, q = j / n;
@@ -1081,11 +1142,17 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 				shadow.tfar = (float)vlen(to_light);
 				n_shadow++;
 				Best dummy;
-				if (trace<true, PACKET>(sc, shadow, stack, dummy))
+				TM_END(TM_LIGHT_SETUP, t_lsetup);
+				TM_BEGIN(t_shadow);
+				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy);
+				TM_END(TM_TRACE_SHADOW, t_shadow);
+				if (occluded)
 					continue;
+				TM_BEGIN(t_shade);
 				c3 diff_col = diff_colour(light, *mat, light_dir, normal);
 				c3 spec_col = spec_colour(light, *mat, cam_dir, light_dir, normal);
 				light_total = cadd(light_total, cadd(diff_col, spec_col));
+				TM_END(TM_SHADE, t_shade);
 			}
 			light_total = cscale((float)(1.0 / (double)(n * n)), light_total);
 			total = cadd(total, light_total);
@@ -1097,6 +1164,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	}
 
 	// Compact the spawning lanes: one slot reservation per wave.
+	TM_BEGIN(t_spawn);
 	if (io.queue_out) {
 		unsigned want = (unsigned)n_children;
 		unsigned prefix = want;
@@ -1161,6 +1229,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			}
 		}
 	}
+	TM_END(TM_SPAWN, t_spawn);
 	return total;
 }
 
@@ -1259,7 +1328,14 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 {
 	// one traversal stack per wave (packet traversal)
 	__shared__ int4 s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
+	__shared__ __attribute__((aligned(16))) float s_sum[RT_BLOCK / 64][3 * 64];
 	int *stack = reinterpret_cast<int *>(s_stack + (threadIdx.x >> 6) * RT_MAX_STACK);
+#ifdef RT_TIMING
+	if ((threadIdx.x & 63) < TM_COUNT)
+		s_timing[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+#endif
+	TM_BEGIN(t_kernel);
+	TM_BEGIN(t_setup);
 	unsigned long long local = (unsigned long long)blockIdx.x * RT_BLOCK + threadIdx.x;
 	unsigned long long sample = sample_first + local;
 	int px = 0, py = 0, k = 0;
@@ -1283,8 +1359,10 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	}
 	unsigned n_shadow = 0, n_env = 0;
 	c3 weight = { 1.0f, 1.0f, 1.0f };
+	TM_END(TM_SETUP, t_setup);
 	c3 total = shade_vertex<true>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env);
 
+	TM_BEGIN(t_tail);
 	const unsigned lane = lane_id();
 	if (64 % sc.spp == 0) {
 		// All samples of a pixel sit in consecutive lanes of this wave: add them in
@@ -1292,10 +1370,30 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		const unsigned spp = (unsigned)sc.spp;
 		const unsigned base = lane - lane % spp;
 		float ar = total.r, ag = total.g, ab = total.b;
-		for (unsigned j = 1; j < spp; j++) {
-			ar += __shfl(total.r, (int)(base + j), 64);
-			ag += __shfl(total.g, (int)(base + j), 64);
-			ab += __shfl(total.b, (int)(base + j), 64);
+		if (spp % 4 == 0) {
+			// through LDS: one lane per (pixel, channel) walks its run of samples
+			float *sw = s_sum[threadIdx.x >> 6];
+			sw[lane] = total.r; sw[64 + lane] = total.g; sw[128 + lane] = total.b;
+			const unsigned ppw = 64 / spp;
+			if (lane < 3 * ppw) {
+				float *run = sw + 64 * (lane / ppw) + (lane % ppw) * spp;
+				const float4 *src = reinterpret_cast<const float4 *>(run);
+				float4 v = src[0];
+				float acc = v.x;
+				acc += v.y; acc += v.z; acc += v.w;
+				for (unsigned j = 1; j < spp / 4; j++) {
+					v = src[j];
+					acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+				}
+				run[0] = acc;
+			}
+			ar = sw[base]; ag = sw[64 + base]; ab = sw[128 + base];
+		} else {
+			for (unsigned j = 1; j < spp; j++) {
+				ar += __shfl(total.r, (int)(base + j), 64);
+				ag += __shfl(total.g, (int)(base + j), 64);
+				ab += __shfl(total.b, (int)(base + j), 64);
+			}
 		}
 		if (active && lane == base) {
 			if (direct_out) {
@@ -1335,9 +1433,18 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 			if (b) atomicAdd(p + 2, (unsigned long long)b);
 		}
 	}
-	wave_count_add(&counters->rays_primary, active ? 1u : 0u);
+	const u64 active_lanes = __builtin_amdgcn_ballot_w64(active), env_lanes = __builtin_amdgcn_ballot_w64(n_env != 0);
+	if (lane == 0) {
+		if (active_lanes) atomicAdd(&counters->rays_primary, (unsigned long long)__builtin_popcountll(active_lanes));
+		if (env_lanes) atomicAdd(&counters->env_lookups, (unsigned long long)__builtin_popcountll(env_lanes));
+	}
 	wave_count_add(&counters->rays_shadow, n_shadow);
-	wave_count_add(&counters->env_lookups, n_env);
+	TM_END(TM_TAIL, t_tail);
+	TM_END(TM_KERNEL, t_kernel);
+#ifdef RT_TIMING
+	if ((threadIdx.x & 63) < TM_COUNT)
+		atomicAdd(&g_timing[threadIdx.x & 63], s_timing[threadIdx.x >> 6][threadIdx.x & 63]);
+#endif
 }
 
 // One bounce: every queued ray is traced and shaded like a primary one
@@ -1387,13 +1494,21 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 	wave_count_add(&counters->env_lookups, n_env);
 }
 
-#ifdef RT_TRAVERSAL_STATS
+#if defined(RT_TRAVERSAL_STATS) || defined(RT_TIMING)
 __global__ void k_collect_stats(DevCounters *counters)
 {
+#ifdef RT_TRAVERSAL_STATS
 	counters->bvh_nodes = g_stat_nodes;
 	counters->tri_tests = g_stat_tris;
 	g_stat_nodes = 0;
 	g_stat_tris = 0;
+#endif
+#ifdef RT_TIMING
+	for (int i = 0; i < TM_COUNT; i++) {
+		printf("timing %d %llu\n", i, g_timing[i]);
+		g_timing[i] = 0;
+	}
+#endif
 }
 #endif
 
@@ -1565,12 +1680,21 @@ hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, u
 		return hipSuccess;
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long blocks = (pixel_count + 255) / 256;
-#ifdef RT_TRAVERSAL_STATS
-	hipLaunchKernelGGL(k_collect_stats, dim3(1), dim3(1), 0, stream, const_cast<DevCounters *>(counters));
-#endif
 	hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, stream, sc, tm, pixel_first, pixel_count,
 			accum, colour);
 	return hipGetLastError();
+}
+
+// Build options only: moves the traversal statistics into the counter block.
+hipError_t rt_launch_collect_stats(DevCounters *counters, hipStream_t stream)
+{
+#if defined(RT_TRAVERSAL_STATS) || defined(RT_TIMING)
+	hipLaunchKernelGGL(k_collect_stats, dim3(1), dim3(1), 0, stream, counters);
+	return hipGetLastError();
+#else
+	(void)counters; (void)stream;
+	return hipSuccess;
+#endif
 }
 
 hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
