@@ -243,6 +243,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	sc->fixed_consumption = !any_area && !any_glossy;
 	sc->glossy = any_glossy;
 	d.any_reflective = any_reflective && h.max_reflections >= 1;
+	d.any_area_light = any_area && h.shadow_samples >= 2;
 
 	// Meshes: leaf-ordered triangle and normal arrays, one BVH each.
 	std::vector<DevMesh> meshes(h.num_meshes);

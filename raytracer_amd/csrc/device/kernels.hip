@@ -55,7 +55,7 @@ DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_
 // uninstrumented kernel.
 #ifdef RT_TIMING
 enum { TM_KERNEL, TM_SETUP, TM_TRACE_PRIMARY, TM_FINISH, TM_LIGHT_SETUP, TM_TRACE_SHADOW, TM_SHADE, TM_ENV,
-	TM_SPAWN, TM_TAIL,
+	TM_SPAWN, TM_TAIL, TM_SHAFT, TM_BOUNDS,
 	TM_IN_BBOX, TM_IN_XFORM, TM_IN_PRIM, TM_IN_MESH_SETUP, TM_IN_NODES, TM_IN_LEAVES, TM_IN_POP, TM_IN_SELECT,
 	TM_SHADOW_OFFSET = 8, TM_COUNT = TM_IN_SELECT + 1 + TM_SHADOW_OFFSET };
 __device__ unsigned long long g_timing[TM_COUNT];
@@ -524,6 +524,9 @@ DEV float next_up(float x)
 // whether ray_intersect would return true, shading.c:48).
 #ifdef RT_TRAVERSAL_STATS
 __device__ unsigned long long g_stat_nodes, g_stat_tris;
+// per wave, light and surface: [0..CAP] leaves listed, [CAP+1] list overflow, [CAP+2] surface culled,
+// [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
+__device__ unsigned long long g_stat_shaft[24];
 #endif
 
 template <bool ANYHIT>
@@ -837,16 +840,306 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 	}
 }
 
+// ---- light shafts -------------------------------------------------------------
+//
+// The n x n shadow rays a lane sends to an area light (shading.c:22-47) all start
+// within 1e-4 of the lane's hit point, and the hit points of a wave lie within a
+// pixel's footprint.  Every one of these 64 x n^2 segments stays inside the
+// "shaft" swept by a box that moves from the bounding box of the wave's origins
+// to the bounding box of the light's parallelogram while its half-size changes
+// linearly (convexity: a point at fraction s of a segment lies within
+// (1-s) r0 + s r1 of the centre line, per axis).  Once per wave and light the
+// shaft is tested against the scene: surfaces whose box it misses are skipped by
+// all of these rays, and for a mesh the BVH leaves it touches are collected into
+// a short list in LDS.  A shadow ray then tests exactly the triangles of the
+// listed leaves (after a per-ray box test of each leaf) instead of descending
+// the BVH from the root n^2 times.  The outcome per ray is unchanged: a triangle
+// the ray can hit lies in a leaf the shaft touches, and the triangle test and
+// the acceptance window are the same.
+#ifndef RT_SHAFT
+#define RT_SHAFT 1
+#endif
+#define RT_SHAFT_CAP 16        // leaves per list; a fuller shaft falls back to the BVH walk
+#define RT_SHAFT_LISTS 4       // mesh surfaces (in traversal order) that get a list
+
+struct ShaftEntry {
+	float lox, loy, loz, hix, hiy, hiz;
+	int ref, pad;
+};
+
+// Per axis, the shaft's upper edge u0 + s gU must reach the box's low plane and
+// its lower edge d0 + s gD must not pass the high plane, for one s in [0, 1].
+// Each plane gives a bound on s, evaluated as fma(plane, 1/g, -x0/g) like the ray
+// slab distances, with the rounding error e = 2^-20 + |x0/g| 2^-22 (window [0,1]).
+struct ShaftAxis {
+	float iU, kU, eU, iD, kD, eD;
+	bool pU, pD;
+};
+struct ShaftTest {
+	ShaftAxis x, y, z;
+};
+
+struct ShaftState {
+	u64 cull;            // bit si: no ray of this wave and light can pass the surface's box
+	unsigned counts;     // 8 bits per listed mesh: number of leaves, 0xff = no list
+	const ShaftEntry *lists;
+};
+
+DEV ShaftAxis shaft_axis(double c0, double r0, double c1, double r1)
+{
+	ShaftAxis a;
+	const double u0 = c0 + r0, d0 = c0 - r0;
+	float gU = (float)((c1 + r1) - u0), gD = (float)((c1 - r1) - d0);
+	if (__builtin_fabsf(gU) < 1e-30f) gU = __builtin_copysignf(1e-30f, gU);
+	if (__builtin_fabsf(gD) < 1e-30f) gD = __builtin_copysignf(1e-30f, gD);
+	a.iU = 1.0f / gU;
+	a.iD = 1.0f / gD;
+	a.kU = (float)(-(u0 * (double)a.iU));
+	a.kD = (float)(-(d0 * (double)a.iD));
+	a.eU = 9.5367431640625e-7f + __builtin_fabsf(a.kU) * 2.384185791015625e-7f;
+	a.eD = 9.5367431640625e-7f + __builtin_fabsf(a.kD) * 2.384185791015625e-7f;
+	a.pU = gU > 0;
+	a.pD = gD > 0;
+	return a;
+}
+
+// Half-sizes grow by 2^-18 of the coordinates' magnitude: covers the rounding of
+// the bounds themselves and the float tolerance of the reference's own box and
+// triangle tests (a ray that misses a box by less can still be accepted there).
+DEV d3 shaft_inflate(d3 c, d3 r)
+{
+	const double k = 3.814697265625e-06;
+	return { r.x + k * (__builtin_fabs(c.x) + r.x), r.y + k * (__builtin_fabs(c.y) + r.y),
+		r.z + k * (__builtin_fabs(c.z) + r.z) };
+}
+
+DEV ShaftTest shaft_make(d3 c0, d3 r0, d3 c1, d3 r1)
+{
+	r0 = shaft_inflate(c0, r0);
+	r1 = shaft_inflate(c1, r1);
+	ShaftTest st;
+	st.x = shaft_axis(c0.x, r0.x, c1.x, r1.x);
+	st.y = shaft_axis(c0.y, r0.y, c1.y, r1.y);
+	st.z = shaft_axis(c0.z, r0.z, c1.z, r1.z);
+	return st;
+}
+
+DEV void shaft_axis_bounds(const ShaftAxis &a, float lo, float hi, float &smin, float &smax)
+{
+	const float inf = __builtin_huge_valf();
+	const float tU = __builtin_fmaf(lo, a.iU, a.kU);
+	const float tD = __builtin_fmaf(hi, a.iD, a.kD);
+	// s gU >= lo - u0: a lower bound on s when gU > 0, an upper bound otherwise
+	smin = __builtin_fmaxf(smin, a.pU ? tU - a.eU : -inf);
+	smax = __builtin_fminf(smax, a.pU ? inf : tU + a.eU);
+	// s gD <= hi - d0: an upper bound when gD > 0, a lower bound otherwise
+	smax = __builtin_fminf(smax, a.pD ? tD + a.eD : inf);
+	smin = __builtin_fmaxf(smin, a.pD ? -inf : tD - a.eD);
+}
+
+DEV bool shaft_box(const ShaftTest &st, float lox, float loy, float loz, float hix, float hiy, float hiz)
+{
+	float smin = 0.0f, smax = 1.0f;
+	shaft_axis_bounds(st.x, lox, hix, smin, smax);
+	shaft_axis_bounds(st.y, loy, hiy, smin, smax);
+	shaft_axis_bounds(st.z, loz, hiz, smin, smax);
+	return smin <= smax;
+}
+
+// Shaft ends in the model space of an affine surface: the image of a box under
+// p -> A p + T lies in the box with centre A c + T and half-size |A| r.
+DEV void shaft_to_model(CSurface &s, d3 c, d3 r, d3 &cm, d3 &rm)
+{
+	const CONSTAS double *m = s.w2m;
+	cm.x = M4(m, 0, 0) * c.x + M4(m, 0, 1) * c.y + M4(m, 0, 2) * c.z + M4(m, 0, 3);
+	cm.y = M4(m, 1, 0) * c.x + M4(m, 1, 1) * c.y + M4(m, 1, 2) * c.z + M4(m, 1, 3);
+	cm.z = M4(m, 2, 0) * c.x + M4(m, 2, 1) * c.y + M4(m, 2, 2) * c.z + M4(m, 2, 3);
+	rm.x = __builtin_fabs(M4(m, 0, 0)) * r.x + __builtin_fabs(M4(m, 0, 1)) * r.y + __builtin_fabs(M4(m, 0, 2)) * r.z;
+	rm.y = __builtin_fabs(M4(m, 1, 0)) * r.x + __builtin_fabs(M4(m, 1, 1)) * r.y + __builtin_fabs(M4(m, 1, 2)) * r.z;
+	rm.z = __builtin_fabs(M4(m, 2, 0)) * r.x + __builtin_fabs(M4(m, 2, 1)) * r.y + __builtin_fabs(M4(m, 2, 2)) * r.z;
+}
+
+// Collects the leaves of a mesh whose box the shaft touches.  Everything here
+// is wave-uniform.  Returns the number of leaves, or -1 when there are more than
+// RT_SHAFT_CAP (or the mesh is a single leaf): the caller then walks the BVH.
+DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int *wstack_i, ShaftEntry *out)
+{
+	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
+	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
+	const bool writer = lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+	int ref = __builtin_amdgcn_readfirstlane(mesh.root);
+	if (ref < 0)
+		return -1;
+	int sp = 0, n = 0;
+	for (;;) {
+		RT_STAT(if (writer) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 4], 1ull));
+		const float4 q0 = cload(nodes, 4 * ref + 0), q1 = cload(nodes, 4 * ref + 1);
+		const float4 q2 = cload(nodes, 4 * ref + 2), q3 = cload(nodes, 4 * ref + 3);
+		const bool h0 = __builtin_amdgcn_ballot_w64(shaft_box(st, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y)) != 0;
+		const bool h1 = __builtin_amdgcn_ballot_w64(shaft_box(st, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w)) != 0;
+		const int c0 = as_i(q3.x), c1 = as_i(q3.y);
+		int next = 0;
+		bool have_next = false;
+		if (h0) {
+			if (c0 < 0) {
+				if (n == RT_SHAFT_CAP)
+					return -1;
+				if (writer)
+					out[n] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, c0, 0 };
+				n++;
+			} else {
+				next = c0;
+				have_next = true;
+			}
+		}
+		if (h1) {
+			if (c1 < 0) {
+				if (n == RT_SHAFT_CAP)
+					return -1;
+				if (writer)
+					out[n] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c1, 0 };
+				n++;
+			} else if (have_next) {
+				if (sp == RT_MAX_STACK)
+					return -1;
+				if (writer)
+					wstack[sp] = make_int4(c1, 0, 0, 0);
+				sp++;
+			} else {
+				next = c1;
+				have_next = true;
+			}
+		}
+		if (!have_next) {
+			if (sp == 0)
+				return n;
+			sp--;
+			next = __builtin_amdgcn_readfirstlane(wstack[sp].x);
+		}
+		ref = next;
+	}
+}
+
+// Any-hit over a shaft's leaf list: the per-ray part of mesh_traverse_packet<true>
+// with the descent replaced by a walk over the listed leaves.
+DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear, float tfar,
+		const ShaftEntry *list, int count)
+{
+	const CONSTAS DevTriEdges *edges = in_const(sc.edges) + mesh.tri_first;
+	const PacketRay pr = make_packet_ray(o, d, tnear, tfar);
+	const double dnear = (double)tnear, dfar = (double)tfar;
+	bool found = false;
+	for (int c = 0; c < count; c++) {
+		const ShaftEntry e = list[c];
+		float tn;
+		const bool h = packet_box_hit(pr, e.lox, e.loy, e.loz, e.hix, e.hiy, e.hiz, tnear, tfar, tn) && !found;
+		u64 actm = __builtin_amdgcn_ballot_w64(h);
+		if (actm == 0)
+			continue;
+		const int v = ~__builtin_amdgcn_readfirstlane(e.ref);
+		const int first = v >> 2, ntri = (v & 3) + 1;
+		for (int i = 0; i < ntri; i++) {
+			const CONSTAS DevTriEdges &te = edges[first + i];
+			float aa, bb, cc;
+			double t;
+			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
+			const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
+			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, aa, bb, cc, t);
+			if (ok && t >= dnear && t <= dfar)
+				found = true;
+			actm &= ~__builtin_amdgcn_ballot_w64(found);
+			if (actm == 0)
+				break;
+		}
+		if (__builtin_amdgcn_ballot_w64(!found) == 0)
+			break;
+	}
+	return found;
+}
+
+// Builds the shaft of one area light for this wave: `olo`/`ohi` bound the hit
+// points of the participating lanes (wave-uniform).  shading.c:22-47 defines the
+// segments: origin = hit point + 1e-4 dir, end = origin + (float)|to_light| dir,
+// the light point = position + alpha edge1 + beta edge2 with alpha, beta in [0, 2 - 1/n].
+DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float olo[3], const float ohi[3],
+		int *wstack, ShaftEntry *lists)
+{
+	ShaftState ss;
+	ss.cull = 0;
+	ss.counts = 0xffffffffu;
+	ss.lists = lists;
+	// alpha = p/n + drand() reaches (n-1)/n + 1 (shading.c:30-31)
+	const double amax = ((double)((float)(n - 1) / (float)n) + 1.0) * 1.0000002;
+	const d3 lp = ld3(light.position), e1 = vscale(amax, ld3(light.edge1)), e2 = vscale(amax, ld3(light.edge2));
+	const d3 llo = { lp.x + __builtin_fmin(0.0, e1.x) + __builtin_fmin(0.0, e2.x),
+		lp.y + __builtin_fmin(0.0, e1.y) + __builtin_fmin(0.0, e2.y),
+		lp.z + __builtin_fmin(0.0, e1.z) + __builtin_fmin(0.0, e2.z) };
+	const d3 lhi = { lp.x + __builtin_fmax(0.0, e1.x) + __builtin_fmax(0.0, e2.x),
+		lp.y + __builtin_fmax(0.0, e1.y) + __builtin_fmax(0.0, e2.y),
+		lp.z + __builtin_fmax(0.0, e1.z) + __builtin_fmax(0.0, e2.z) };
+	const d3 c0 = { 0.5 * ((double)olo[0] + (double)ohi[0]), 0.5 * ((double)olo[1] + (double)ohi[1]),
+		0.5 * ((double)olo[2] + (double)ohi[2]) };
+	const d3 c1 = { 0.5 * (llo.x + lhi.x), 0.5 * (llo.y + lhi.y), 0.5 * (llo.z + lhi.z) };
+	// the 1e-4 steps at both ends, and the rounding of the segment length to float
+	const double len = __builtin_fabs(c1.x - c0.x) + __builtin_fabs(c1.y - c0.y) + __builtin_fabs(c1.z - c0.z);
+	const double pad0 = 1.1e-4, pad1 = 1.1e-4 + 2.4e-7 * (len + 4.0);
+	const d3 r0 = { 0.5 * ((double)ohi[0] - (double)olo[0]) + pad0, 0.5 * ((double)ohi[1] - (double)olo[1]) + pad0,
+		0.5 * ((double)ohi[2] - (double)olo[2]) + pad0 };
+	const d3 r1 = { 0.5 * (lhi.x - llo.x) + pad1, 0.5 * (lhi.y - llo.y) + pad1, 0.5 * (lhi.z - llo.z) + pad1 };
+	const ShaftTest world = shaft_make(c0, r0, c1, r1);
+	int slot = 0;
+	for (int si = 0; si < sc.num_surfaces; si++) {
+		CSurface &s = in_const(sc.surfaces)[si];
+		const bool is_mesh = s.shape_type == RTAMD_SHAPE_MESH;
+		const int my_slot = slot;
+		if (is_mesh)
+			slot++;
+		const bool touches = __builtin_amdgcn_ballot_w64(shaft_box(world, s.bbox[0], s.bbox[1], s.bbox[2],
+				s.bbox[3], s.bbox[4], s.bbox[5])) != 0;
+		RT_STAT(const bool counter = lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)));
+		if (!touches) {
+			if (si < 64)
+				ss.cull |= 1ull << si;
+			RT_STAT(if (counter) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 2], 1ull));
+			continue;
+		}
+		if (!is_mesh || my_slot >= RT_SHAFT_LISTS || !s.affine) {
+			RT_STAT(if (counter) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 3], 1ull));
+			continue;
+		}
+		d3 cm0, rm0, cm1, rm1;
+		shaft_to_model(s, c0, r0, cm0, rm0);
+		shaft_to_model(s, c1, r1, cm1, rm1);
+		const ShaftTest model = shaft_make(cm0, rm0, cm1, rm1);
+		const int n_leaves = shaft_collect(sc, in_const(sc.meshes)[s.mesh], model, wstack, lists + my_slot * RT_SHAFT_CAP);
+		RT_STAT(if (counter) atomicAdd(&g_stat_shaft[n_leaves >= 0 ? n_leaves : RT_SHAFT_CAP + 1], 1ull));
+		if (n_leaves >= 0)
+			ss.counts = (ss.counts & ~(0xffu << (8 * my_slot))) | ((unsigned)n_leaves << (8 * my_slot));
+	}
+	return ss;
+}
+
 // ---- ray.c:483-578 + 643-672 ---------------------------------------------------
 
 template <bool ANYHIT, bool PACKET>
-DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
+DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const ShaftState *shaft = nullptr)
 {
 	best.surface = -1;
 	best.tri = -1;
 	best.t = __builtin_huge_valf();
+	int mesh_slot = 0;
 	for (int si = 0; si < sc.num_surfaces; si++) {
 		CSurface &s = in_const(sc.surfaces)[si];
+		int shaft_count = 0xff;
+		if (ANYHIT && PACKET && shaft) {
+			if (s.shape_type == RTAMD_SHAPE_MESH) {
+				if (mesh_slot < RT_SHAFT_LISTS)
+					shaft_count = (int)((shaft->counts >> (8 * mesh_slot)) & 0xffu);
+				mesh_slot++;
+			}
+			if (si < 64 && ((shaft->cull >> si) & 1))
+				continue;
+		}
 		float bnear, bfar;
 		TM2_BEGIN(t_bbox);
 		const bool in_box = surface_bbox_test(s.bbox, ray, bnear, bfar);
@@ -872,7 +1165,12 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best)
 		default: {
 			int orig;
 			double t;
-			if (PACKET)
+			if (ANYHIT && PACKET && shaft_count != 0xff) {
+				// every listed leaf's triangles; a hit's t lies in [bnear, bfar]
+				hits = mesh_candidates_anyhit(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar,
+						shaft->lists + (mesh_slot - 1) * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
+				t = (double)bnear;
+			} else if (PACKET)
 				hits = mesh_traverse_packet<ANYHIT>(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar, stack,
 						tri, orig, t, ba, bb, bc) ? 1 : 0;
 			else
@@ -1064,6 +1362,7 @@ struct ShadeIO {
 	unsigned *queue_count;
 	unsigned queue_capacity;
 	DevCounters *counters;
+	ShaftEntry *shaft_lists;     // this wave's leaf lists in LDS, or null
 };
 
 template <bool PACKET>
@@ -1085,6 +1384,26 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			finish_hit(sc, ray, best, position, normal);
 		TM_END(TM_FINISH, t_finish);
 	}
+	// bounds of the wave's hit points (origins of its shadow rays), rounded outwards
+	float olo[3] = { 0, 0, 0 }, ohi[3] = { 0, 0, 0 };
+	const bool shafts = RT_SHAFT && PACKET && io.shaft_lists && sc.any_area_light;
+	TM_BEGIN(t_bounds);
+	if (shafts) {
+		const float inf = __builtin_huge_valf();
+		const double pv[3] = { position.x, position.y, position.z };
+		for (int a = 0; a < 3; a++) {
+			const float f = (float)pv[a];
+			const float w = __builtin_fabsf(f) * 1.1920929e-7f + 1e-37f;
+			float lo = hit ? f - w : inf, hi = hit ? f + w : -inf;
+			for (int off = 32; off > 0; off >>= 1) {
+				lo = __builtin_fminf(lo, __shfl_xor(lo, off, 64));
+				hi = __builtin_fmaxf(hi, __shfl_xor(hi, off, 64));
+			}
+			olo[a] = as_f(__builtin_amdgcn_readfirstlane(as_i(lo)));
+			ohi[a] = as_f(__builtin_amdgcn_readfirstlane(as_i(hi)));
+		}
+	}
+	TM_END(TM_BOUNDS, t_bounds);
 	if (rec && active) {
 		rtamd_hit_record r;
 		r.surface = hit ? best.surface : -1;
@@ -1121,6 +1440,13 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			const int n = area ? sc.shadow_samples : 1;
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
 			d3 lpos = ld3(light.position);
+			ShaftState shaft_state;
+			const bool use_shaft = shafts && area && n >= 2;
+			if (use_shaft) {
+				TM_BEGIN(t_shaft);
+				shaft_state = shaft_build(sc, light, n, olo, ohi, stack, io.shaft_lists);
+				TM_END(TM_SHAFT, t_shaft);
+			}
 			for (int j = 0; j < n * n; j++) {
 				TM_BEGIN(t_lsetup);
 				d3 light_pos = lpos;
@@ -1144,7 +1470,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 				Best dummy;
 				TM_END(TM_LIGHT_SETUP, t_lsetup);
 				TM_BEGIN(t_shadow);
-				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy);
+				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy, use_shaft ? &shaft_state : nullptr);
 				TM_END(TM_TRACE_SHADOW, t_shadow);
 				if (occluded)
 					continue;
@@ -1350,7 +1676,8 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		sample_offsets(sc, rng_mode, glibc_table, seed, px, py, k, key, offx, offy);
 		ray = camera_ray(sc, px, py, offx, offy);
 	}
-	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters };
+	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_LISTS * RT_SHAFT_CAP];
+	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters, s_shaft[threadIdx.x >> 6] };
 	rtamd_hit_record *rec = nullptr;
 	if (hits && active) {
 		// window-local record index
@@ -1466,7 +1793,7 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 	// every lane of a wave runs the same number of iterations (the wave-level
 	// compaction inside shade_vertex needs all 64 lanes present)
 	const unsigned rounds = (count + stride - 1) / stride;
-	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters };
+	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, nullptr };
 	unsigned n_shadow = 0, n_env = 0, n_rays = 0;
 	for (unsigned round = 0; round < rounds; round++) {
 		unsigned idx = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1502,6 +1829,11 @@ __global__ void k_collect_stats(DevCounters *counters)
 	counters->tri_tests = g_stat_tris;
 	g_stat_nodes = 0;
 	g_stat_tris = 0;
+	for (int i = 0; i < 24; i++) {
+		if (g_stat_shaft[i])
+			printf("shaft %d %llu\n", i, g_stat_shaft[i]);
+		g_stat_shaft[i] = 0;
+	}
 #endif
 #ifdef RT_TIMING
 	for (int i = 0; i < TM_COUNT; i++) {

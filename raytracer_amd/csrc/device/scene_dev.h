@@ -104,6 +104,7 @@ struct DevScene {
 	float cam_d;               /* `d = near` narrowed to float, ray.c:32 */
 	float background[3];
 	int32_t num_lights, num_surfaces, has_cubemap, any_reflective;
+	int32_t any_area_light, pad0;
 	const DevLight *lights;
 	const DevSurface *surfaces;
 	const DevMaterial *materials;
