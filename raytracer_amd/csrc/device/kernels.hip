@@ -527,6 +527,13 @@ __device__ unsigned long long g_stat_nodes, g_stat_tris;
 // per wave, light and surface: [0..CAP] leaves listed, [CAP+1] list overflow, [CAP+2] surface culled,
 // [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
 __device__ unsigned long long g_stat_shaft[24];
+// wave-level event counts: see the EV_ names
+__device__ unsigned long long g_stat_ev[16];
+enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
+	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS, EV_CULLED };
+#define RT_EV(e) do { if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], 1ull); } while (0)
+#else
+#define RT_EV(e) do { } while (0)
 #endif
 
 template <bool ANYHIT>
@@ -635,9 +642,9 @@ DEV float4 cload(const_f4 p, int i)
 }
 
 // Float ray for the packet box tests.  A slab distance (plane - o) / d is
-// evaluated as fma(plane, i, k) with i = 1/d and k = -o * i, both rounded to
-// float.  Against the exact distance T the result is off by at most
-// |T| * 2^-22 + |o * i| * 2^-23 (rounding of d, of 1/d, of k and of the fma), so
+// evaluated as fma(plane, i, k) with i = 1/d (hardware reciprocal, 1 ulp) and
+// k = -o * i, both floats.  Against the exact distance T the result is off by at
+// most |T| * 2^-21 + |o * i| * 2^-23 (rounding of d, of 1/d, of k and of the fma), so
 // for distances inside a window [tlo, thi] the error is below
 //   E = max(|tlo|, |thi|) * 2^-20 + max|k| * 2^-22,
 // and a box whose true overlap with the window is not empty always satisfies
@@ -656,7 +663,8 @@ DEV PacketRay make_packet_ray(d3 o, d3 d, float tlo, float thi)
 	if (__builtin_fabsf(fx) < 1e-30f) fx = __builtin_copysignf(1e-30f, fx);
 	if (__builtin_fabsf(fy) < 1e-30f) fy = __builtin_copysignf(1e-30f, fy);
 	if (__builtin_fabsf(fz) < 1e-30f) fz = __builtin_copysignf(1e-30f, fz);
-	r.ix = 1.0f / fx; r.iy = 1.0f / fy; r.iz = 1.0f / fz;
+	// 1-ulp reciprocals: i = (1/d)(1 + 2^-22) at worst, inside the error budget above
+	r.ix = __builtin_amdgcn_rcpf(fx); r.iy = __builtin_amdgcn_rcpf(fy); r.iz = __builtin_amdgcn_rcpf(fz);
 	r.kx = (float)(-(o.x * (double)r.ix));
 	r.ky = (float)(-(o.y * (double)r.iy));
 	r.kz = (float)(-(o.z * (double)r.iz));
@@ -700,6 +708,7 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 	bool maybe = act && !((b_approx < -1e-30f && b_approx > -big) || (b_approx > 1.0001f && b_approx < big));
 	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
 		return false;
+	RT_EV(EV_TRI_STAGE2);
 	d3 qvec = vcross(tvec, edge1);
 	const double x2 = vdot(d, qvec);
 	const float c_approx = (float)x2 * rdet;
@@ -708,6 +717,7 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big));
 	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
 		return false;
+	RT_EV(EV_TRI_EXACT);
 	bool ok = false;
 	if (maybe) {
 		bb = (float)(x1 / (double)det);
@@ -870,10 +880,14 @@ struct ShaftEntry {
 // Per axis, the shaft's upper edge u0 + s gU must reach the box's low plane and
 // its lower edge d0 + s gD must not pass the high plane, for one s in [0, 1].
 // Each plane gives a bound on s, evaluated as fma(plane, 1/g, -x0/g) like the ray
-// slab distances, with the rounding error e = 2^-20 + |x0/g| 2^-22 (window [0,1]).
+// slab distances, with the rounding error e = 2^-20 + |x0/g| 2^-22 (window [0,1])
+// folded into the constant.  Whether a plane bounds s from below or from above
+// depends on the sign of g, which is fixed per shaft: each plane gets one
+// coefficient pair for each role, and the pair of the role it does not play is
+// (0, -inf) or (0, +inf), which leaves the bound untouched.
 struct ShaftAxis {
-	float iU, kU, eU, iD, kD, eD;
-	bool pU, pD;
+	float loU_i, loU_k, hiU_i, hiU_k;    // low plane (upper edge): as a lower / as an upper bound
+	float loD_i, loD_k, hiD_i, hiD_k;    // high plane (lower edge)
 };
 struct ShaftTest {
 	ShaftAxis x, y, z;
@@ -888,18 +902,23 @@ struct ShaftState {
 DEV ShaftAxis shaft_axis(double c0, double r0, double c1, double r1)
 {
 	ShaftAxis a;
+	const float inf = __builtin_huge_valf();
 	const double u0 = c0 + r0, d0 = c0 - r0;
 	float gU = (float)((c1 + r1) - u0), gD = (float)((c1 - r1) - d0);
 	if (__builtin_fabsf(gU) < 1e-30f) gU = __builtin_copysignf(1e-30f, gU);
 	if (__builtin_fabsf(gD) < 1e-30f) gD = __builtin_copysignf(1e-30f, gD);
-	a.iU = 1.0f / gU;
-	a.iD = 1.0f / gD;
-	a.kU = (float)(-(u0 * (double)a.iU));
-	a.kD = (float)(-(d0 * (double)a.iD));
-	a.eU = 9.5367431640625e-7f + __builtin_fabsf(a.kU) * 2.384185791015625e-7f;
-	a.eD = 9.5367431640625e-7f + __builtin_fabsf(a.kD) * 2.384185791015625e-7f;
-	a.pU = gU > 0;
-	a.pD = gD > 0;
+	const float iU = 1.0f / gU, iD = 1.0f / gD;
+	const float kU = (float)(-(u0 * (double)iU)), kD = (float)(-(d0 * (double)iD));
+	const float eU = 9.5367431640625e-7f + __builtin_fabsf(kU) * 2.384185791015625e-7f;
+	const float eD = 9.5367431640625e-7f + __builtin_fabsf(kD) * 2.384185791015625e-7f;
+	// s gU >= lo - u0: a lower bound on s when gU > 0, an upper bound otherwise
+	const bool pU = gU > 0;
+	a.loU_i = pU ? iU : 0.0f;  a.loU_k = pU ? kU - eU : -inf;
+	a.hiU_i = pU ? 0.0f : iU;  a.hiU_k = pU ? inf : kU + eU;
+	// s gD <= hi - d0: an upper bound when gD > 0, a lower bound otherwise
+	const bool pD = gD > 0;
+	a.hiD_i = pD ? iD : 0.0f;  a.hiD_k = pD ? kD + eD : inf;
+	a.loD_i = pD ? 0.0f : iD;  a.loD_k = pD ? -inf : kD - eD;
 	return a;
 }
 
@@ -926,15 +945,8 @@ DEV ShaftTest shaft_make(d3 c0, d3 r0, d3 c1, d3 r1)
 
 DEV void shaft_axis_bounds(const ShaftAxis &a, float lo, float hi, float &smin, float &smax)
 {
-	const float inf = __builtin_huge_valf();
-	const float tU = __builtin_fmaf(lo, a.iU, a.kU);
-	const float tD = __builtin_fmaf(hi, a.iD, a.kD);
-	// s gU >= lo - u0: a lower bound on s when gU > 0, an upper bound otherwise
-	smin = __builtin_fmaxf(smin, a.pU ? tU - a.eU : -inf);
-	smax = __builtin_fminf(smax, a.pU ? inf : tU + a.eU);
-	// s gD <= hi - d0: an upper bound when gD > 0, a lower bound otherwise
-	smax = __builtin_fminf(smax, a.pD ? tD + a.eD : inf);
-	smin = __builtin_fmaxf(smin, a.pD ? -inf : tD - a.eD);
+	smin = __builtin_fmaxf(smin, __builtin_fmaxf(__builtin_fmaf(lo, a.loU_i, a.loU_k), __builtin_fmaf(hi, a.loD_i, a.loD_k)));
+	smax = __builtin_fminf(smax, __builtin_fminf(__builtin_fmaf(lo, a.hiU_i, a.hiU_k), __builtin_fmaf(hi, a.hiD_i, a.hiD_k)));
 }
 
 DEV bool shaft_box(const ShaftTest &st, float lox, float loy, float loz, float hix, float hiy, float hiz)
@@ -1031,6 +1043,7 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 	bool found = false;
 	for (int c = 0; c < count; c++) {
 		const ShaftEntry e = list[c];
+		RT_EV(EV_LIST_BOX);
 		float tn;
 		const bool h = packet_box_hit(pr, e.lox, e.loy, e.loz, e.hix, e.hiy, e.hiz, tnear, tfar, tn) && !found;
 		u64 actm = __builtin_amdgcn_ballot_w64(h);
@@ -1137,9 +1150,12 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 					shaft_count = (int)((shaft->counts >> (8 * mesh_slot)) & 0xffu);
 				mesh_slot++;
 			}
-			if (si < 64 && ((shaft->cull >> si) & 1))
+			if (si < 64 && ((shaft->cull >> si) & 1)) {
+				RT_EV(EV_CULLED);
 				continue;
+			}
 		}
+		RT_EV(ANYHIT ? EV_BBOX_SHADOW : EV_BBOX_PRIMARY);
 		float bnear, bfar;
 		TM2_BEGIN(t_bbox);
 		const bool in_box = surface_bbox_test(s.bbox, ray, bnear, bfar);
@@ -1156,6 +1172,8 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 		int hits;
 		int tri = -1;
 		float ba = 0, bb = 0, bc = 0;
+		if (s.shape_type != RTAMD_SHAPE_MESH)
+			RT_EV(ANYHIT ? EV_PRIM_SHADOW : EV_PRIM_PRIMARY);
 		switch (s.shape_type) {
 		case RTAMD_SHAPE_PLANE: hits = plane_intersect(s, o, d, ts, nc); break;
 		case RTAMD_SHAPE_DISK: hits = disk_intersect(s, o, d, bnear, ts, nc); break;
@@ -1166,14 +1184,16 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 			int orig;
 			double t;
 			if (ANYHIT && PACKET && shaft_count != 0xff) {
+				RT_EV(EV_MESH_LIST_SHADOW);
 				// every listed leaf's triangles; a hit's t lies in [bnear, bfar]
 				hits = mesh_candidates_anyhit(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar,
 						shaft->lists + (mesh_slot - 1) * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
 				t = (double)bnear;
-			} else if (PACKET)
+			} else if (PACKET) {
+				RT_EV(ANYHIT ? EV_MESH_WALK_SHADOW : EV_MESH_WALK_PRIMARY);
 				hits = mesh_traverse_packet<ANYHIT>(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar, stack,
 						tri, orig, t, ba, bb, bc) ? 1 : 0;
-			else
+			} else
 				hits = mesh_traverse<ANYHIT>(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar, stack,
 						tri, orig, t, ba, bb, bc) ? 1 : 0;
 			ts[0] = (float)t;                       // ray.c:471
@@ -1467,6 +1487,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 				shadow.tnear = 0;
 				shadow.tfar = (float)vlen(to_light);
 				n_shadow++;
+				RT_EV(EV_SHADOW_RAYS);
 				Best dummy;
 				TM_END(TM_LIGHT_SETUP, t_lsetup);
 				TM_BEGIN(t_shadow);
@@ -1475,6 +1496,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 				if (occluded)
 					continue;
 				TM_BEGIN(t_shade);
+				RT_EV(EV_SHADE);
 				c3 diff_col = diff_colour(light, *mat, light_dir, normal);
 				c3 spec_col = spec_colour(light, *mat, cam_dir, light_dir, normal);
 				light_total = cadd(light_total, cadd(diff_col, spec_col));
@@ -1641,7 +1663,7 @@ DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_t
 // on the 1080p showcase frame); the bounce kernel keeps per-lane stacks in LDS
 // (32 KB per workgroup) and runs at four.
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 5
+#define RT_MIN_WAVES 4
 #endif
 #ifndef RT_MIN_WAVES_BOUNCE
 #define RT_MIN_WAVES_BOUNCE 4
@@ -1833,6 +1855,11 @@ __global__ void k_collect_stats(DevCounters *counters)
 		if (g_stat_shaft[i])
 			printf("shaft %d %llu\n", i, g_stat_shaft[i]);
 		g_stat_shaft[i] = 0;
+	}
+	for (int i = 0; i < 16; i++) {
+		if (g_stat_ev[i])
+			printf("event %d %llu\n", i, g_stat_ev[i]);
+		g_stat_ev[i] = 0;
 	}
 #endif
 #ifdef RT_TIMING
