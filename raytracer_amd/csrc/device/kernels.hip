@@ -899,18 +899,28 @@ struct ShaftState {
 	const ShaftEntry *lists;
 };
 
-DEV ShaftAxis shaft_axis(double c0, double r0, double c1, double r1)
+struct f3 { float x, y, z; };
+
+// All shaft arithmetic is float: the half-sizes are inflated by 2^-18 of the
+// coordinates' magnitude first, which is far more than the few 2^-24 roundings
+// of the operations below can move an edge, and also covers the float tolerance
+// of the reference's own box and triangle tests (a ray that misses a box by
+// less than that can still be accepted there).
+DEV ShaftAxis shaft_axis(float c0, float r0, float c1, float r1)
 {
+	const float infl = 3.814697265625e-06f;
+	r0 += infl * (__builtin_fabsf(c0) + r0);
+	r1 += infl * (__builtin_fabsf(c1) + r1);
 	ShaftAxis a;
 	const float inf = __builtin_huge_valf();
-	const double u0 = c0 + r0, d0 = c0 - r0;
-	float gU = (float)((c1 + r1) - u0), gD = (float)((c1 - r1) - d0);
+	const float u0 = c0 + r0, d0 = c0 - r0;
+	float gU = (c1 + r1) - u0, gD = (c1 - r1) - d0;
 	if (__builtin_fabsf(gU) < 1e-30f) gU = __builtin_copysignf(1e-30f, gU);
 	if (__builtin_fabsf(gD) < 1e-30f) gD = __builtin_copysignf(1e-30f, gD);
-	const float iU = 1.0f / gU, iD = 1.0f / gD;
-	const float kU = (float)(-(u0 * (double)iU)), kD = (float)(-(d0 * (double)iD));
-	const float eU = 9.5367431640625e-7f + __builtin_fabsf(kU) * 2.384185791015625e-7f;
-	const float eD = 9.5367431640625e-7f + __builtin_fabsf(kD) * 2.384185791015625e-7f;
+	const float iU = __builtin_amdgcn_rcpf(gU), iD = __builtin_amdgcn_rcpf(gD);
+	const float kU = -(u0 * iU), kD = -(d0 * iD);
+	const float eU = 9.5367431640625e-7f + __builtin_fabsf(kU) * 4.76837158203125e-7f;
+	const float eD = 9.5367431640625e-7f + __builtin_fabsf(kD) * 4.76837158203125e-7f;
 	// s gU >= lo - u0: a lower bound on s when gU > 0, an upper bound otherwise
 	const bool pU = gU > 0;
 	a.loU_i = pU ? iU : 0.0f;  a.loU_k = pU ? kU - eU : -inf;
@@ -922,20 +932,8 @@ DEV ShaftAxis shaft_axis(double c0, double r0, double c1, double r1)
 	return a;
 }
 
-// Half-sizes grow by 2^-18 of the coordinates' magnitude: covers the rounding of
-// the bounds themselves and the float tolerance of the reference's own box and
-// triangle tests (a ray that misses a box by less can still be accepted there).
-DEV d3 shaft_inflate(d3 c, d3 r)
+DEV ShaftTest shaft_make(f3 c0, f3 r0, f3 c1, f3 r1)
 {
-	const double k = 3.814697265625e-06;
-	return { r.x + k * (__builtin_fabs(c.x) + r.x), r.y + k * (__builtin_fabs(c.y) + r.y),
-		r.z + k * (__builtin_fabs(c.z) + r.z) };
-}
-
-DEV ShaftTest shaft_make(d3 c0, d3 r0, d3 c1, d3 r1)
-{
-	r0 = shaft_inflate(c0, r0);
-	r1 = shaft_inflate(c1, r1);
 	ShaftTest st;
 	st.x = shaft_axis(c0.x, r0.x, c1.x, r1.x);
 	st.y = shaft_axis(c0.y, r0.y, c1.y, r1.y);
@@ -960,15 +958,21 @@ DEV bool shaft_box(const ShaftTest &st, float lox, float loy, float loz, float h
 
 // Shaft ends in the model space of an affine surface: the image of a box under
 // p -> A p + T lies in the box with centre A c + T and half-size |A| r.
-DEV void shaft_to_model(CSurface &s, d3 c, d3 r, d3 &cm, d3 &rm)
+DEV void shaft_to_model(CSurface &s, f3 c, f3 r, f3 &cm, f3 &rm)
 {
 	const CONSTAS double *m = s.w2m;
-	cm.x = M4(m, 0, 0) * c.x + M4(m, 0, 1) * c.y + M4(m, 0, 2) * c.z + M4(m, 0, 3);
-	cm.y = M4(m, 1, 0) * c.x + M4(m, 1, 1) * c.y + M4(m, 1, 2) * c.z + M4(m, 1, 3);
-	cm.z = M4(m, 2, 0) * c.x + M4(m, 2, 1) * c.y + M4(m, 2, 2) * c.z + M4(m, 2, 3);
-	rm.x = __builtin_fabs(M4(m, 0, 0)) * r.x + __builtin_fabs(M4(m, 0, 1)) * r.y + __builtin_fabs(M4(m, 0, 2)) * r.z;
-	rm.y = __builtin_fabs(M4(m, 1, 0)) * r.x + __builtin_fabs(M4(m, 1, 1)) * r.y + __builtin_fabs(M4(m, 1, 2)) * r.z;
-	rm.z = __builtin_fabs(M4(m, 2, 0)) * r.x + __builtin_fabs(M4(m, 2, 1)) * r.y + __builtin_fabs(M4(m, 2, 2)) * r.z;
+	const float m00 = (float)M4(m, 0, 0), m01 = (float)M4(m, 0, 1), m02 = (float)M4(m, 0, 2), m03 = (float)M4(m, 0, 3);
+	const float m10 = (float)M4(m, 1, 0), m11 = (float)M4(m, 1, 1), m12 = (float)M4(m, 1, 2), m13 = (float)M4(m, 1, 3);
+	const float m20 = (float)M4(m, 2, 0), m21 = (float)M4(m, 2, 1), m22 = (float)M4(m, 2, 2), m23 = (float)M4(m, 2, 3);
+	cm.x = m00 * c.x + m01 * c.y + m02 * c.z + m03;
+	cm.y = m10 * c.x + m11 * c.y + m12 * c.z + m13;
+	cm.z = m20 * c.x + m21 * c.y + m22 * c.z + m23;
+	// the matrix entries and the sums are rounded: 2^-20 of the terms' magnitude on top
+	const float k = 9.5367431640625e-7f;
+	const float bx = r.x + k * __builtin_fabsf(c.x), by = r.y + k * __builtin_fabsf(c.y), bz = r.z + k * __builtin_fabsf(c.z);
+	rm.x = __builtin_fabsf(m00) * bx + __builtin_fabsf(m01) * by + __builtin_fabsf(m02) * bz + k * __builtin_fabsf(m03);
+	rm.y = __builtin_fabsf(m10) * bx + __builtin_fabsf(m11) * by + __builtin_fabsf(m12) * bz + k * __builtin_fabsf(m13);
+	rm.z = __builtin_fabsf(m20) * bx + __builtin_fabsf(m21) * by + __builtin_fabsf(m22) * bz + k * __builtin_fabsf(m23);
 }
 
 // Collects the leaves of a mesh whose box the shaft touches.  Everything here
@@ -1082,23 +1086,28 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 	ss.counts = 0xffffffffu;
 	ss.lists = lists;
 	// alpha = p/n + drand() reaches (n-1)/n + 1 (shading.c:30-31)
-	const double amax = ((double)((float)(n - 1) / (float)n) + 1.0) * 1.0000002;
-	const d3 lp = ld3(light.position), e1 = vscale(amax, ld3(light.edge1)), e2 = vscale(amax, ld3(light.edge2));
-	const d3 llo = { lp.x + __builtin_fmin(0.0, e1.x) + __builtin_fmin(0.0, e2.x),
-		lp.y + __builtin_fmin(0.0, e1.y) + __builtin_fmin(0.0, e2.y),
-		lp.z + __builtin_fmin(0.0, e1.z) + __builtin_fmin(0.0, e2.z) };
-	const d3 lhi = { lp.x + __builtin_fmax(0.0, e1.x) + __builtin_fmax(0.0, e2.x),
-		lp.y + __builtin_fmax(0.0, e1.y) + __builtin_fmax(0.0, e2.y),
-		lp.z + __builtin_fmax(0.0, e1.z) + __builtin_fmax(0.0, e2.z) };
-	const d3 c0 = { 0.5 * ((double)olo[0] + (double)ohi[0]), 0.5 * ((double)olo[1] + (double)ohi[1]),
-		0.5 * ((double)olo[2] + (double)ohi[2]) };
-	const d3 c1 = { 0.5 * (llo.x + lhi.x), 0.5 * (llo.y + lhi.y), 0.5 * (llo.z + lhi.z) };
-	// the 1e-4 steps at both ends, and the rounding of the segment length to float
-	const double len = __builtin_fabs(c1.x - c0.x) + __builtin_fabs(c1.y - c0.y) + __builtin_fabs(c1.z - c0.z);
-	const double pad0 = 1.1e-4, pad1 = 1.1e-4 + 2.4e-7 * (len + 4.0);
-	const d3 r0 = { 0.5 * ((double)ohi[0] - (double)olo[0]) + pad0, 0.5 * ((double)ohi[1] - (double)olo[1]) + pad0,
-		0.5 * ((double)ohi[2] - (double)olo[2]) + pad0 };
-	const d3 r1 = { 0.5 * (lhi.x - llo.x) + pad1, 0.5 * (lhi.y - llo.y) + pad1, 0.5 * (lhi.z - llo.z) + pad1 };
+	const float amax = ((float)(n - 1) / (float)n + 1.0f) * 1.000001f;
+	const f3 lp = { (float)light.position[0], (float)light.position[1], (float)light.position[2] };
+	const f3 e1 = { amax * (float)light.edge1[0], amax * (float)light.edge1[1], amax * (float)light.edge1[2] };
+	const f3 e2 = { amax * (float)light.edge2[0], amax * (float)light.edge2[1], amax * (float)light.edge2[2] };
+	const f3 llo = { lp.x + __builtin_fminf(0.0f, e1.x) + __builtin_fminf(0.0f, e2.x),
+		lp.y + __builtin_fminf(0.0f, e1.y) + __builtin_fminf(0.0f, e2.y),
+		lp.z + __builtin_fminf(0.0f, e1.z) + __builtin_fminf(0.0f, e2.z) };
+	const f3 lhi = { lp.x + __builtin_fmaxf(0.0f, e1.x) + __builtin_fmaxf(0.0f, e2.x),
+		lp.y + __builtin_fmaxf(0.0f, e1.y) + __builtin_fmaxf(0.0f, e2.y),
+		lp.z + __builtin_fmaxf(0.0f, e1.z) + __builtin_fmaxf(0.0f, e2.z) };
+	const f3 c0 = { 0.5f * (olo[0] + ohi[0]), 0.5f * (olo[1] + ohi[1]), 0.5f * (olo[2] + ohi[2]) };
+	const f3 c1 = { 0.5f * (llo.x + lhi.x), 0.5f * (llo.y + lhi.y), 0.5f * (llo.z + lhi.z) };
+	// the 1e-4 steps at both ends, the rounding of the segment length to float, and
+	// the roundings of the bounds above (2^-20 of the magnitudes involved)
+	const float len = __builtin_fabsf(c1.x - c0.x) + __builtin_fabsf(c1.y - c0.y) + __builtin_fabsf(c1.z - c0.z);
+	const float k = 9.5367431640625e-7f;
+	const float pad0 = 1.1e-4f, pad1 = 1.1e-4f + k * (len + 4.0f);
+	const f3 r0 = { 0.5f * (ohi[0] - olo[0]) + pad0 + k * __builtin_fabsf(c0.x), 0.5f * (ohi[1] - olo[1]) + pad0 + k * __builtin_fabsf(c0.y),
+		0.5f * (ohi[2] - olo[2]) + pad0 + k * __builtin_fabsf(c0.z) };
+	const f3 r1 = { 0.5f * (lhi.x - llo.x) + pad1 + k * (__builtin_fabsf(llo.x) + __builtin_fabsf(lhi.x)),
+		0.5f * (lhi.y - llo.y) + pad1 + k * (__builtin_fabsf(llo.y) + __builtin_fabsf(lhi.y)),
+		0.5f * (lhi.z - llo.z) + pad1 + k * (__builtin_fabsf(llo.z) + __builtin_fabsf(lhi.z)) };
 	const ShaftTest world = shaft_make(c0, r0, c1, r1);
 	int slot = 0;
 	for (int si = 0; si < sc.num_surfaces; si++) {
@@ -1120,7 +1129,7 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 			RT_STAT(if (counter) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 3], 1ull));
 			continue;
 		}
-		d3 cm0, rm0, cm1, rm1;
+		f3 cm0, rm0, cm1, rm1;
 		shaft_to_model(s, c0, r0, cm0, rm0);
 		shaft_to_model(s, c1, r1, cm1, rm1);
 		const ShaftTest model = shaft_make(cm0, rm0, cm1, rm1);
