@@ -1394,10 +1394,13 @@ struct ShadeIO {
 	ShaftEntry *shaft_lists;     // this wave's leaf lists in LDS, or null
 };
 
-template <bool PACKET>
+// `ray_again` returns the incoming direction once more (recomputed or re-read by
+// the caller): it is needed again only when a reflection is spawned, after all the
+// shadow rays, and is not worth six registers until then.
+template <bool PACKET, typename RayAgain>
 DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t key, c3 weight,
 		uint32_t slot, bool active, int *stack, rtamd_hit_record *rec,
-		unsigned &n_shadow, unsigned &n_env)
+		unsigned &n_shadow, unsigned &n_env, RayAgain ray_again)
 {
 	const DevScene &sc = *io.sc;
 	c3 total = { 0.0f, 0.0f, 0.0f };
@@ -1544,8 +1547,9 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 					atomicAdd(&io.counters->queue_overflow, 1ull);
 				} else {
 					// shading.c:81-84
-					double dn = vdot(ray.d, normal);
-					d3 rdir = vadd(ray.d, vscale(-2 * dn, normal));           // vector.c:77-81
+					const d3 in_dir = ray_again();
+					double dn = vdot(in_dir, normal);
+					d3 rdir = vadd(in_dir, vscale(-2 * dn, normal));          // vector.c:77-81
 					d3 rorg = vadd(position, vscale(1e-2, rdir));
 					c3 w = cmul(lc3(mat->specular), { mat->reflect, mat->reflect, mat->reflect });
 					w = cmul(w, weight);
@@ -1718,7 +1722,25 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	unsigned n_shadow = 0, n_env = 0;
 	c3 weight = { 1.0f, 1.0f, 1.0f };
 	TM_END(TM_SETUP, t_setup);
-	c3 total = shade_vertex<true>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env);
+	auto ray_again = [&]() {
+		// same arithmetic from the same inputs: the same bits as `ray.d`
+		unsigned tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
+		int qx = 0, qy = 0, qk = 0;
+		uint32_t qslot, qkey;
+		float ox, oy;
+		sample_to_pixel(tm, sc.spp, sample_first + (unsigned long long)blockIdx.x * RT_BLOCK + tid, qx, qy, qk, qslot);
+		sample_offsets(sc, rng_mode, glibc_table, seed, qx, qy, qk, qkey, ox, oy);
+		return camera_ray(sc, qx, qy, ox, oy).d;
+	};
+	c3 total = shade_vertex<true>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env, ray_again);
+	{
+		// the pixel mapping again, rather than five registers kept through the kernel
+		unsigned tid = threadIdx.x;
+		asm volatile("" : "+v"(tid));
+		const unsigned long long l2 = (unsigned long long)blockIdx.x * RT_BLOCK + tid;
+		active = l2 < sample_count && sample_to_pixel(tm, sc.spp, sample_first + l2, px, py, k, slot);
+	}
 
 	TM_BEGIN(t_tail);
 	const unsigned lane = lane_id();
@@ -1843,7 +1865,13 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 			slot = it.slot; key = it.key; depth = it.depth;
 			n_rays++;
 		}
-		c3 total = shade_vertex<false>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env);
+		auto ray_again = [&]() {
+			unsigned i = idx;
+			asm volatile("" : "+v"(i));
+			const double *dq = queue_in[i].d;
+			return d3{ dq[0], dq[1], dq[2] };
+		};
+		c3 total = shade_vertex<false>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env, ray_again);
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}
