@@ -1681,6 +1681,9 @@ DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_t
 #ifndef RT_MIN_WAVES_BOUNCE
 #define RT_MIN_WAVES_BOUNCE 4
 #endif
+#ifndef RT_BOUNCE_PACKET
+#define RT_BOUNCE_PACKET 0
+#endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES)
 k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
 		int rng_mode, uint32_t seed, const int32_t *glibc_table, long long *accum, float *direct_out,
@@ -1835,8 +1838,18 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
 k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count, unsigned queue_capacity,
 		long long *accum, QueueItem *queue_out, unsigned *queue_out_count, DevCounters *counters)
 {
+#if RT_BOUNCE_PACKET
+	// consecutive queue entries come from the lanes of one spawning wave (one
+	// pixel's samples): they are coherent enough to walk the BVH as a packet
+	__shared__ int4 s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
+	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_LISTS * RT_SHAFT_CAP];
+	int *stack = reinterpret_cast<int *>(s_stack + (threadIdx.x >> 6) * RT_MAX_STACK);
+	ShaftEntry *shaft_lists = s_shaft[threadIdx.x >> 6];
+#else
 	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
 	int *stack = s_stack + threadIdx.x;
+	ShaftEntry *shaft_lists = nullptr;
+#endif
 	unsigned count = *queue_in_count;
 	if (count > queue_capacity)
 		count = queue_capacity;
@@ -1846,7 +1859,7 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 	// every lane of a wave runs the same number of iterations (the wave-level
 	// compaction inside shade_vertex needs all 64 lanes present)
 	const unsigned rounds = (count + stride - 1) / stride;
-	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, nullptr };
+	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, shaft_lists };
 	unsigned n_shadow = 0, n_env = 0, n_rays = 0;
 	for (unsigned round = 0; round < rounds; round++) {
 		unsigned idx = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1871,7 +1884,7 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 			const double *dq = queue_in[i].d;
 			return d3{ dq[0], dq[1], dq[2] };
 		};
-		c3 total = shade_vertex<false>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env, ray_again);
+		c3 total = shade_vertex<RT_BOUNCE_PACKET != 0>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env, ray_again);
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}

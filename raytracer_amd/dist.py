@@ -58,11 +58,17 @@ def gather_frame(frame, base_params, rank, world, group=None):
     if world == 1:
         return frame
     mine = _pack(frame, owner_params(base_params, rank, world))
+    # gloo moves host memory: device buffers are staged through the host there
+    # (only used to rehearse the multi-rank path on one GPU; RCCL takes them as they are)
+    staged = mine.is_cuda and dist.get_backend(group) == "gloo"
+    if staged:
+        mine = mine.cpu()
     bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, bufs, dst=0, group=group)
     if rank == 0:
         for r in range(1, world):
-            _unpack(bufs[r], frame, owner_params(base_params, r, world))
+            buf = bufs[r].to(frame.device) if staged else bufs[r]
+            _unpack(buf, frame, owner_params(base_params, r, world))
     return frame
 
 
