@@ -56,13 +56,16 @@ struct Builder {
 	int max_depth = 0;
 	bool sah;
 
+#ifndef RT_MAX_LEAF
+#define RT_MAX_LEAF 2
+#endif
 	static int leaf_ref(int first, int count) { return ~((first << 2) | (count - 1)); }
 
 	// Returns a child reference (node index, or leaf encoding).
 	int build(int first, int count, int depth)
 	{
 		max_depth = std::max(max_depth, depth);
-		if (count <= 4)
+		if (count <= RT_MAX_LEAF)
 			return leaf_ref(first, count);
 
 		Box cb;

@@ -22,6 +22,17 @@
 
 namespace {
 
+// Light shafts (see shaft_build): compile-time switches and capacities.
+#ifndef RT_SHAFT
+#define RT_SHAFT 1
+#endif
+#ifndef RT_SHAFT_CAP
+#define RT_SHAFT_CAP 24        // leaves per list; a fuller shaft falls back to the BVH walk
+#endif
+#ifndef RT_SHAFT_LISTS
+#define RT_SHAFT_LISTS 4       // mesh surfaces (in traversal order) that get a list
+#endif
+
 #ifdef RT_TRAVERSAL_STATS
 #define RT_STAT(x) x
 #else
@@ -526,7 +537,7 @@ DEV float next_up(float x)
 __device__ unsigned long long g_stat_nodes, g_stat_tris;
 // per wave, light and surface: [0..CAP] leaves listed, [CAP+1] list overflow, [CAP+2] surface culled,
 // [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
-__device__ unsigned long long g_stat_shaft[24];
+__device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
 // wave-level event counts: see the EV_ names
 __device__ unsigned long long g_stat_ev[16];
 enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
@@ -866,11 +877,6 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 // the BVH from the root n^2 times.  The outcome per ray is unchanged: a triangle
 // the ray can hit lies in a leaf the shaft touches, and the triangle test and
 // the acceptance window are the same.
-#ifndef RT_SHAFT
-#define RT_SHAFT 1
-#endif
-#define RT_SHAFT_CAP 16        // leaves per list; a fuller shaft falls back to the BVH walk
-#define RT_SHAFT_LISTS 4       // mesh surfaces (in traversal order) that get a list
 
 struct ShaftEntry {
 	float lox, loy, loz, hix, hiy, hiz;
@@ -1901,7 +1907,7 @@ __global__ void k_collect_stats(DevCounters *counters)
 	counters->tri_tests = g_stat_tris;
 	g_stat_nodes = 0;
 	g_stat_tris = 0;
-	for (int i = 0; i < 24; i++) {
+	for (int i = 0; i < RT_SHAFT_CAP + 8; i++) {
 		if (g_stat_shaft[i])
 			printf("shaft %d %llu\n", i, g_stat_shaft[i]);
 		g_stat_shaft[i] = 0;
