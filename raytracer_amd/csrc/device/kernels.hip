@@ -1149,8 +1149,18 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 
 // ---- ray.c:483-578 + 643-672 ---------------------------------------------------
 
+DEV ShaftState shaft_none()
+{
+	ShaftState ss;
+	ss.cull = 0;
+	ss.counts = 0xffffffffu;
+	ss.lists = nullptr;
+	return ss;
+}
+
+// `shaft` is passed by value: taking its address would pin it in scratch memory.
 template <bool ANYHIT, bool PACKET>
-DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const ShaftState *shaft = nullptr)
+DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const ShaftState shaft)
 {
 	best.surface = -1;
 	best.tri = -1;
@@ -1159,13 +1169,13 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 	for (int si = 0; si < sc.num_surfaces; si++) {
 		CSurface &s = in_const(sc.surfaces)[si];
 		int shaft_count = 0xff;
-		if (ANYHIT && PACKET && shaft) {
+		if (ANYHIT && PACKET) {
 			if (s.shape_type == RTAMD_SHAPE_MESH) {
 				if (mesh_slot < RT_SHAFT_LISTS)
-					shaft_count = (int)((shaft->counts >> (8 * mesh_slot)) & 0xffu);
+					shaft_count = (int)((shaft.counts >> (8 * mesh_slot)) & 0xffu);
 				mesh_slot++;
 			}
-			if (si < 64 && ((shaft->cull >> si) & 1)) {
+			if (si < 64 && ((shaft.cull >> si) & 1)) {
 				RT_EV(EV_CULLED);
 				continue;
 			}
@@ -1202,7 +1212,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 				RT_EV(EV_MESH_LIST_SHADOW);
 				// every listed leaf's triangles; a hit's t lies in [bnear, bfar]
 				hits = mesh_candidates_anyhit(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar,
-						shaft->lists + (mesh_slot - 1) * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
+						shaft.lists + (mesh_slot - 1) * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
 				t = (double)bnear;
 			} else if (PACKET) {
 				RT_EV(ANYHIT ? EV_MESH_WALK_SHADOW : EV_MESH_WALK_PRIMARY);
@@ -1415,7 +1425,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
 	if (active) {
 		TM_BEGIN(t_trace);
-		hit = trace<false, PACKET>(sc, ray, stack, best);
+		hit = trace<false, PACKET>(sc, ray, stack, best, shaft_none());
 		TM_END(TM_TRACE_PRIMARY, t_trace);
 		TM_BEGIN(t_finish);
 		if (hit)
@@ -1478,7 +1488,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			const int n = area ? sc.shadow_samples : 1;
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
 			d3 lpos = ld3(light.position);
-			ShaftState shaft_state;
+			ShaftState shaft_state = shaft_none();
 			const bool use_shaft = shafts && area && n >= 2;
 			if (use_shaft) {
 				TM_BEGIN(t_shaft);
@@ -1509,7 +1519,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 				Best dummy;
 				TM_END(TM_LIGHT_SETUP, t_lsetup);
 				TM_BEGIN(t_shadow);
-				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy, use_shaft ? &shaft_state : nullptr);
+				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy, shaft_state);
 				TM_END(TM_TRACE_SHADOW, t_shadow);
 				if (occluded)
 					continue;
@@ -1972,7 +1982,7 @@ k_trace(DevScene sc, const double *rays, unsigned long long n, rtamd_hit_record 
 	r.surface = -1; r.triangle = -1; r.t = 0; r.pad = 0;
 	r.position[0] = r.position[1] = r.position[2] = 0;
 	r.normal[0] = r.normal[1] = r.normal[2] = 0;
-	if (trace<false, false>(sc, ray, stack, best)) {
+	if (trace<false, false>(sc, ray, stack, best, shaft_none())) {
 		d3 position, normal;
 		finish_hit(sc, ray, best, position, normal);
 		r.surface = best.surface;
