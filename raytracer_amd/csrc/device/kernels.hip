@@ -59,6 +59,20 @@ template <typename T> __device__ __forceinline__ const CONSTAS T *in_const(const
 
 DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+#ifdef RT_TRAVERSAL_STATS
+__device__ unsigned long long g_stat_nodes, g_stat_tris;
+// per wave, light and surface: [0..CAP] leaves listed, [CAP+1] list overflow, [CAP+2] surface culled,
+// [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
+__device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
+// wave-level event counts: see the EV_ names
+__device__ unsigned long long g_stat_ev[16];
+enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
+	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS, EV_CULLED };
+#define RT_EV(e) do { if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], 1ull); } while (0)
+#else
+#define RT_EV(e) do { } while (0)
+#endif
+
 // Build option RT_TIMING=1|2: per-wave cycle counts per code region (1: the
 // stages of a sample, 2: also the inside of trace()), summed over the launch
 // and printed by k_collect_stats.  The counter reads perturb what they measure
@@ -463,58 +477,6 @@ DEV bool triangle_intersect(d3 o, d3 d, const float4 &p0, const float4 &p1, cons
 	return true;
 }
 
-// Float ray used only for the BVH box tests.  The boxes are exact (float-valued
-// vertices); what is rounded is the ray, so each slab distance is pushed
-// outwards: the origin is moved by its own rounding error away from the box
-// side being tested, and the entry/exit distances get a relative margin that
-// covers the rounding of 1/d, the subtraction and the product.
-struct BoxRay {
-	float onx, ony, onz;      // origin used for entry planes
-	float ofx, ofy, ofz;      // origin used for exit planes
-	float ix, iy, iz;         // 1/d
-	bool sx, sy, sz;          // d < 0
-};
-
-DEV BoxRay make_box_ray(d3 o, d3 d)
-{
-	BoxRay r;
-	float fx = (float)d.x, fy = (float)d.y, fz = (float)d.z;
-	// a zero component would turn (plane - o) * inf into NaN on the plane itself
-	if (__builtin_fabsf(fx) < 1e-30f) fx = __builtin_copysignf(1e-30f, fx);
-	if (__builtin_fabsf(fy) < 1e-30f) fy = __builtin_copysignf(1e-30f, fy);
-	if (__builtin_fabsf(fz) < 1e-30f) fz = __builtin_copysignf(1e-30f, fz);
-	r.ix = 1.0f / fx; r.iy = 1.0f / fy; r.iz = 1.0f / fz;
-	r.sx = fx < 0; r.sy = fy < 0; r.sz = fz < 0;
-	float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-	const float ulp = 1.1920929e-7f;      // 2^-23 >= the rounding error of the narrowing
-	float px = __builtin_fabsf(ox) * ulp, py = __builtin_fabsf(oy) * ulp, pz = __builtin_fabsf(oz) * ulp;
-	// entry distance (plane - o) * i must not grow: move o towards +d, exit the other way
-	r.onx = r.sx ? ox - px : ox + px;  r.ofx = r.sx ? ox + px : ox - px;
-	r.ony = r.sy ? oy - py : oy + py;  r.ofy = r.sy ? oy + py : oy - py;
-	r.onz = r.sz ? oz - pz : oz + pz;  r.ofz = r.sz ? oz + pz : oz - pz;
-	return r;
-}
-
-// Conservative slab test; returns the (widened) entry distance in tn.
-DEV bool box_test(const BoxRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
-		float tlo, float thi, float &tn)
-{
-	const float margin = 9.5367431640625e-7f;   // 2^-20
-	float nx = ((r.sx ? hix : lox) - r.onx) * r.ix;
-	float ny = ((r.sy ? hiy : loy) - r.ony) * r.iy;
-	float nz = ((r.sz ? hiz : loz) - r.onz) * r.iz;
-	float fx = ((r.sx ? lox : hix) - r.ofx) * r.ix;
-	float fy = ((r.sy ? loy : hiy) - r.ofy) * r.iy;
-	float fz = ((r.sz ? loz : hiz) - r.ofz) * r.iz;
-	float tnn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
-	float tff = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-	tnn = __builtin_fmaf(-__builtin_fabsf(tnn), margin, tnn);
-	tff = __builtin_fmaf(__builtin_fabsf(tff), margin, tff);
-	tn = __builtin_fmaxf(tnn, tlo);
-	float tf = __builtin_fminf(tff, thi);
-	return tn <= tf;
-}
-
 DEV float as_f(int v) { return __builtin_bit_cast(float, v); }
 DEV int as_i(float v) { return __builtin_bit_cast(int, v); }
 // smallest float strictly above a finite x
@@ -525,103 +487,6 @@ DEV float next_up(float x)
 	int i = as_i(x);
 	i += x > 0.0f ? 1 : -1;
 	return as_f(i);
-}
-
-// Nearest triangle of a mesh inside [tnear, tfar] (effective result of
-// ray.c:360-462: smallest t among triangles that pass the barycentric tests;
-// equal t -> the triangle with the highest index in the mesh's own array, which
-// is what the kd leaf loop's `<=` at ray.c:376 gives inside a leaf).
-// ANYHIT: stop at the first acceptable triangle (shadow rays only need to know
-// whether ray_intersect would return true, shading.c:48).
-#ifdef RT_TRAVERSAL_STATS
-__device__ unsigned long long g_stat_nodes, g_stat_tris;
-// per wave, light and surface: [0..CAP] leaves listed, [CAP+1] list overflow, [CAP+2] surface culled,
-// [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
-__device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
-// wave-level event counts: see the EV_ names
-__device__ unsigned long long g_stat_ev[16];
-enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
-	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS, EV_CULLED };
-#define RT_EV(e) do { if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], 1ull); } while (0)
-#else
-#define RT_EV(e) do { } while (0)
-#endif
-
-template <bool ANYHIT>
-DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear, float tfar,
-		int *stack, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
-{
-	const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes + mesh.node_first);
-	const float4 *tris = reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first);
-	const BoxRay br = make_box_ray(o, d);
-	const double dnear = (double)tnear, dfar = (double)tfar;
-	bool found = false;
-	best_t = __builtin_huge_val();
-	best_orig = -1;
-	best_tri = -1;
-	float limit = tfar;          // float upper bound of the search window, >= best_t
-	int sp = 0;
-	int ref = mesh.root;
-	for (;;) {
-		if (ref >= 0) {
-			RT_STAT(atomicAdd(&g_stat_nodes, 1ull));
-			const float4 q0 = nodes[4 * ref + 0], q1 = nodes[4 * ref + 1];
-			const float4 q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
-			float tn0, tn1;
-			bool h0 = box_test(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0);
-			bool h1 = box_test(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1);
-			int c0 = as_i(q3.x), c1 = as_i(q3.y);
-			if (h0 && h1) {
-				bool swap = tn1 < tn0;
-				int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-				if (sp < RT_MAX_STACK) {
-					stack[sp * RT_BLOCK] = farc;
-					sp++;
-				}
-				ref = nearc;
-				continue;
-			} else if (h0) {
-				ref = c0;
-				continue;
-			} else if (h1) {
-				ref = c1;
-				continue;
-			}
-		} else {
-			int v = ~ref;
-			int first = v >> 2, count = (v & 3) + 1;
-			for (int i = 0; i < count; i++) {
-				const float4 p0 = tris[3 * (first + i) + 0];
-				const float4 p1 = tris[3 * (first + i) + 1];
-				const float4 p2 = tris[3 * (first + i) + 2];
-				float aa, bb, cc;
-				double t;
-				RT_STAT(atomicAdd(&g_stat_tris, 1ull));
-				if (!triangle_intersect(o, d, p0, p1, p2, aa, bb, cc, t))
-					continue;
-				int orig = as_i(p0.w);
-				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
-					best_t = t;
-					best_orig = orig;
-					best_tri = first + i;
-					ba = aa; bb_ = bb; bc = cc;
-					found = true;
-					if (ANYHIT)
-						return true;
-					// next float above or equal to t: boxes further than this cannot win
-					float ft = (float)t;
-					if ((double)ft < t)
-						ft = next_up(ft);
-					limit = ft < tfar ? ft : tfar;
-				}
-			}
-		}
-		if (sp == 0)
-			break;
-		sp--;
-		ref = stack[sp * RT_BLOCK];
-	}
-	return found;
 }
 
 // ---- packet traversal ---------------------------------------------------------
@@ -742,6 +607,90 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 		}
 	}
 	return ok;
+}
+
+// Nearest triangle of a mesh inside [tnear, tfar] (effective result of
+// ray.c:360-462: smallest t among triangles that pass the barycentric tests;
+// equal t -> the triangle with the highest index in the mesh's own array, which
+// is what the kd leaf loop's `<=` at ray.c:376 gives inside a leaf).
+// ANYHIT: stop at the first acceptable triangle (shadow rays only need to know
+// whether ray_intersect would return true, shading.c:48).
+
+template <bool ANYHIT>
+DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear, float tfar,
+		int *stack, int &best_tri, int &best_orig, double &best_t, float &ba, float &bb_, float &bc)
+{
+	const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes + mesh.node_first);
+	const float4 *tris = reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first);
+	const PacketRay br = make_packet_ray(o, d, tnear, tfar);
+	const double dnear = (double)tnear, dfar = (double)tfar;
+	bool found = false;
+	best_t = __builtin_huge_val();
+	best_orig = -1;
+	best_tri = -1;
+	float limit = tfar;          // float upper bound of the search window, >= best_t
+	int sp = 0;
+	int ref = mesh.root;
+	for (;;) {
+		if (ref >= 0) {
+			RT_STAT(atomicAdd(&g_stat_nodes, 1ull));
+			const float4 q0 = nodes[4 * ref + 0], q1 = nodes[4 * ref + 1];
+			const float4 q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
+			float tn0, tn1;
+			bool h0 = packet_box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0);
+			bool h1 = packet_box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1);
+			int c0 = as_i(q3.x), c1 = as_i(q3.y);
+			if (h0 && h1) {
+				bool swap = tn1 < tn0;
+				int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+				if (sp < RT_MAX_STACK) {
+					stack[sp * RT_BLOCK] = farc;
+					sp++;
+				}
+				ref = nearc;
+				continue;
+			} else if (h0) {
+				ref = c0;
+				continue;
+			} else if (h1) {
+				ref = c1;
+				continue;
+			}
+		} else {
+			int v = ~ref;
+			int first = v >> 2, count = (v & 3) + 1;
+			for (int i = 0; i < count; i++) {
+				const float4 p0 = tris[3 * (first + i) + 0];
+				const float4 p1 = tris[3 * (first + i) + 1];
+				const float4 p2 = tris[3 * (first + i) + 2];
+				float aa, bb, cc;
+				double t;
+				RT_STAT(atomicAdd(&g_stat_tris, 1ull));
+				if (!triangle_intersect(o, d, p0, p1, p2, aa, bb, cc, t))
+					continue;
+				int orig = as_i(p0.w);
+				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
+					best_t = t;
+					best_orig = orig;
+					best_tri = first + i;
+					ba = aa; bb_ = bb; bc = cc;
+					found = true;
+					if (ANYHIT)
+						return true;
+					// next float above or equal to t: boxes further than this cannot win
+					float ft = (float)t;
+					if ((double)ft < t)
+						ft = next_up(ft);
+					limit = ft < tfar ? ft : tfar;
+				}
+			}
+		}
+		if (sp == 0)
+			break;
+		sp--;
+		ref = stack[sp * RT_BLOCK];
+	}
+	return found;
 }
 
 template <bool ANYHIT>
