@@ -1343,12 +1343,7 @@ DEV void accumulate(long long *accum, uint32_t slot, c3 c)
 	if (b) atomicAdd(p + 2, (unsigned long long)b);
 }
 
-// ---- shading of one path vertex: shading.c:114-141 without the recursion ------
-//
-// Returns the radiance this vertex contributes directly (environment, or the sum
-// of the light loops) and pushes reflection / glossy children into the bounce
-// queue with their throughput weight.
-
+// What a path vertex needs besides its ray.
 struct ShadeIO {
 	const DevScene *sc;
 	int rng_mode;
@@ -1357,12 +1352,208 @@ struct ShadeIO {
 	unsigned queue_capacity;
 	DevCounters *counters;
 	ShaftEntry *shaft_lists;     // this wave's leaf lists in LDS, or null
+	int *wave_stack;             // transposed light loops: this wave's packet stack in LDS
+	float *wave_sum;             // ... and 384 floats for the ordered sums
 };
+
+// ---- light samples -------------------------------------------------------------
+
+// shading.c:24-37: the point of the light that sample j aims at.
+DEV d3 light_sample_point(const DevScene &sc, CLight &light, bool area, int n, int li, uint32_t key, int j)
+{
+	const d3 lpos = ld3(light.position);
+	if (!area)
+		return lpos;
+	int p = j % n, q = j / n;
+	float alpha = (float)((double)((float)p / (float)n) +
+			keyed_drand(key, PURPOSE_LIGHT0 + (uint32_t)li, 2u * (uint32_t)j));
+	float beta = (float)((double)((float)q / (float)n) +
+			keyed_drand(key, PURPOSE_LIGHT0 + (uint32_t)li, 2u * (uint32_t)j + 1u));
+	return vadd(vadd(lpos, vscale((double)alpha, ld3(light.edge1))), vscale((double)beta, ld3(light.edge2)));
+}
+
+// shading.c:39-46
+DEV Ray shadow_ray_towards(d3 position, d3 light_pos, d3 &light_dir)
+{
+	d3 to_light = vsub(light_pos, position);
+	light_dir = vnorm(to_light);
+	Ray shadow;
+	shadow.d = light_dir;
+	shadow.o = vadd(position, vscale(1e-4, light_dir));
+	shadow.tnear = 0;
+	shadow.tfar = (float)vlen(to_light);
+	return shadow;
+}
+
+DEV double readlane_f64(double v, int lane)
+{
+	const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+	const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+	const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+	return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+DEV d3 readlane_d3(d3 v, int lane) { return { readlane_f64(v.x, lane), readlane_f64(v.y, lane), readlane_f64(v.z, lane) }; }
+
+// The light loops of a wave whose lanes hold UNRELATED hit points (bounced rays).
+// Per lane, the shadow rays of one hit walk the BVH one after the other and the
+// lanes of the wave diverge.  Transposed, the wave takes one hit at a time and
+// its lanes are that hit's light samples: up to 64 shadow rays that leave the
+// same point towards the same light, i.e. a coherent packet (scalar node and
+// triangle fetches, one traversal for all of them).  The samples' contributions
+// are then added in sample order (shading.c:18-54 adds them one by one).  Which
+// form is cheaper depends on samples per light (m) against hits in the wave (H):
+// transposed costs H packet traversals per 64 samples, per lane costs m
+// divergent ones; the form is chosen per wave and light.
+#ifndef RT_TRANSPOSE_GAIN
+#define RT_TRANSPOSE_GAIN 4     // a divergent per-lane step is taken to cost this many packet steps
+#endif
+
+DEV d3 shfl_d3(d3 v, int src)
+{
+	return { __shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64) };
+}
+
+#ifndef RT_TRANSPOSE_MAX_GROUP
+#define RT_TRANSPOSE_MAX_GROUP 8     // most hit points whose samples share one packet
+#endif
+
+template <typename Unused = void>
+DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3 cam_dir, int material,
+		uint32_t key, int *lane_stack, unsigned &n_shadow)
+{
+	const DevScene &sc = *io.sc;
+	const unsigned lane = lane_id();
+	float *sum = io.wave_sum;
+	c3 total = { 0.0f, 0.0f, 0.0f };
+	const u64 lit_lanes = __builtin_amdgcn_ballot_w64(lit);
+	const int hits = __builtin_popcountll(lit_lanes);
+	for (int li = 0; li < sc.num_lights; li++) {
+		CLight &light = in_const(sc.lights)[li];
+		const bool area = light.type == RTAMD_LIGHT_AREA;
+		const int n = area ? sc.shadow_samples : 1;
+		const int m = n * n;
+		const float inv = (float)(1.0 / (double)(n * n));
+		// hit points per packet: as many runs of m lanes as fit into the wave
+		const int group = m >= 64 ? 1 : 64 / m;
+		if (group > RT_TRANSPOSE_MAX_GROUP || (m >= 64 && m * RT_TRANSPOSE_GAIN < hits)) {
+			// per lane, as shade_vertex does it
+			if (lit) {
+				CMaterial &mat = in_const(sc.materials)[material];
+				c3 light_total = { 0.0f, 0.0f, 0.0f };
+				for (int j = 0; j < m; j++) {
+					d3 light_dir;
+					const Ray shadow = shadow_ray_towards(position, light_sample_point(sc, light, area, n, li, key, j), light_dir);
+					n_shadow++;
+					Best dummy;
+					if (trace<true, false>(sc, shadow, lane_stack, dummy, shaft_none()))
+						continue;
+					light_total = cadd(light_total, cadd(diff_colour(light, mat, light_dir, normal),
+							spec_colour(light, mat, cam_dir, light_dir, normal)));
+				}
+				total = cadd(total, cscale(inv, light_total));
+			}
+			continue;
+		}
+		if (m < 64) {
+			// `group` hit points at a time: lane = (run, sample)
+			const int run = (int)lane / m, j = (int)lane - run * m;
+			u64 todo = lit_lanes;
+			while (todo) {
+				const u64 members = todo;
+				int src = 0, taken = 0;
+				for (int k = 0; k < group && todo; k++) {
+					const int hk = __builtin_ctzll(todo);
+					todo &= todo - 1;
+					if (run == k)
+						src = hk;
+					taken++;
+				}
+				const bool valid = run < taken;
+				// the hit point of this lane's run
+				const d3 hp = shfl_d3(position, src), hn = shfl_d3(normal, src), hc = shfl_d3(cam_dir, src);
+				const uint32_t hk = (uint32_t)__shfl((int)key, src, 64);
+				const int hm = __shfl(material, src, 64);
+				c3 c = { 0.0f, 0.0f, 0.0f };
+				if (valid) {
+					CMaterial &mat = in_const(sc.materials)[hm];
+					d3 light_dir;
+					const Ray shadow = shadow_ray_towards(hp, light_sample_point(sc, light, area, n, li, hk, j), light_dir);
+					Best dummy;
+					if (!trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none()))
+						c = cadd(diff_colour(light, mat, light_dir, hn), spec_colour(light, mat, hc, light_dir, hn));
+				}
+				// per run and channel: ((0 + c_0) + c_1) + ... in sample order (shading.c:18-54;
+				// an occluded sample adds +0, which leaves the non-negative sum unchanged)
+				sum[lane] = c.r; sum[64 + lane] = c.g; sum[128 + lane] = c.b;
+				for (int task = (int)lane; task < 3 * taken; task += 64) {
+					const int r = task / 3, ch = task - 3 * r;
+					const float *src_run = sum + 64 * ch + r * m;
+					float a = src_run[0];
+					for (int i = 1; i < m; i++)
+						a += src_run[i];
+					sum[192 + task] = a;
+				}
+				u64 rest = members;
+				for (int k = 0; k < taken; k++) {
+					const int hk2 = __builtin_ctzll(rest);
+					rest &= rest - 1;
+					if ((int)lane == hk2) {
+						total = cadd(total, cscale(inv, { sum[192 + 3 * k], sum[193 + 3 * k], sum[194 + 3 * k] }));
+						n_shadow += (unsigned)m;
+					}
+				}
+			}
+			continue;
+		}
+		// 64 or more samples per light: one hit point at a time, 64 samples per packet
+		u64 todo = lit_lanes;
+		while (todo) {
+			const int h = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const d3 hp = readlane_d3(position, h), hn = readlane_d3(normal, h), hc = readlane_d3(cam_dir, h);
+			const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)key, h);
+			CMaterial &mat = in_const(sc.materials)[__builtin_amdgcn_readlane(material, h)];
+			c3 acc = { 0.0f, 0.0f, 0.0f };      // running sum, identical in every lane
+			for (int base = 0; base < m; base += 64) {
+				const int j = base + (int)lane;
+				c3 c = { 0.0f, 0.0f, 0.0f };
+				if (j < m) {
+					d3 light_dir;
+					const Ray shadow = shadow_ray_towards(hp, light_sample_point(sc, light, area, n, li, hk, j), light_dir);
+					Best dummy;
+					if (!trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none()))
+						c = cadd(diff_colour(light, mat, light_dir, hn), spec_colour(light, mat, hc, light_dir, hn));
+				}
+				const int cnt = m - base < 64 ? m - base : 64;
+				sum[lane] = c.r; sum[64 + lane] = c.g; sum[128 + lane] = c.b;
+				if (lane < 3) {
+					float a = lane == 0 ? acc.r : lane == 1 ? acc.g : acc.b;
+					for (int i = 0; i < cnt; i++)
+						a += sum[64 * lane + i];
+					sum[192 + lane] = a;
+				}
+				acc = { sum[192], sum[193], sum[194] };
+			}
+			if ((int)lane == h) {
+				total = cadd(total, cscale(inv, acc));
+				n_shadow += (unsigned)m;
+			}
+		}
+	}
+	return total;
+}
+
+// ---- shading of one path vertex: shading.c:114-141 without the recursion ------
+//
+// Returns the radiance this vertex contributes directly (environment, or the sum
+// of the light loops) and pushes reflection / glossy children into the bounce
+// queue with their throughput weight.
+
 
 // `ray_again` returns the incoming direction once more (recomputed or re-read by
 // the caller): it is needed again only when a reflection is spawned, after all the
 // shadow rays, and is not worth six registers until then.
-template <bool PACKET, typename RayAgain>
+template <bool PACKET, bool TRANSPOSE, typename RayAgain>
 DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t key, c3 weight,
 		uint32_t slot, bool active, int *stack, rtamd_hit_record *rec,
 		unsigned &n_shadow, unsigned &n_env, RayAgain ray_again)
@@ -1418,6 +1609,8 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 
 	int n_children = 0;
 	CMaterial *mat = nullptr;
+	d3 cam_dir = { 0, 0, 0 };
+	int material = 0;
 	if (active && !hit) {
 		// shading.c:123-129
 		if (sc.has_cubemap) {
@@ -1428,15 +1621,15 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 		} else
 			total = lc3(sc.background);
 	} else if (active) {
-		mat = &in_const(sc.materials)[in_const(sc.surfaces)[best.surface].material];
-		d3 cam_dir = vnorm(vscale(-1, ray.d));                       // shading.c:118
+		material = in_const(sc.surfaces)[best.surface].material;
+		mat = &in_const(sc.materials)[material];
+		cam_dir = vnorm(vscale(-1, ray.d));                          // shading.c:118
 		// shading.c:133-135 -> hit_light_colour, shading.c:7-58
-		for (int li = 0; li < sc.num_lights; li++) {
+		for (int li = 0; !TRANSPOSE && li < sc.num_lights; li++) {
 			CLight &light = in_const(sc.lights)[li];
 			const bool area = light.type == RTAMD_LIGHT_AREA;
 			const int n = area ? sc.shadow_samples : 1;
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
-			d3 lpos = ld3(light.position);
 			ShaftState shaft_state = shaft_none();
 			const bool use_shaft = shafts && area && n >= 2;
 			if (use_shaft) {
@@ -1446,29 +1639,18 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			}
 			for (int j = 0; j < n * n; j++) {
 				TM_BEGIN(t_lsetup);
-				d3 light_pos = lpos;
-				if (area) {
-					int p = j % n, q = j / n;
-					float alpha = (float)((double)((float)p / (float)n) +
-							keyed_drand(key, PURPOSE_LIGHT0 + (uint32_t)li, 2u * (uint32_t)j));
-					float beta = (float)((double)((float)q / (float)n) +
-							keyed_drand(key, PURPOSE_LIGHT0 + (uint32_t)li, 2u * (uint32_t)j + 1u));
-					light_pos = vadd(vadd(lpos, vscale((double)alpha, ld3(light.edge1))),
-							vscale((double)beta, ld3(light.edge2)));
-				}
-				d3 to_light = vsub(light_pos, position);
-				d3 light_dir = vnorm(to_light);
-				Ray shadow;
-				shadow.d = light_dir;
-				shadow.o = vadd(position, vscale(1e-4, light_dir));
-				shadow.tnear = 0;
-				shadow.tfar = (float)vlen(to_light);
+				d3 light_dir;
+				const Ray shadow = shadow_ray_towards(position, light_sample_point(sc, light, area, n, li, key, j), light_dir);
 				n_shadow++;
 				RT_EV(EV_SHADOW_RAYS);
 				Best dummy;
 				TM_END(TM_LIGHT_SETUP, t_lsetup);
 				TM_BEGIN(t_shadow);
+#ifdef RT_EXPERIMENT_NO_SIMT_SHADOWS
+				const bool occluded = PACKET ? trace<true, PACKET>(sc, shadow, stack, dummy, shaft_state) : false;
+#else
 				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy, shaft_state);
+#endif
 				TM_END(TM_TRACE_SHADOW, t_shadow);
 				if (occluded)
 					continue;
@@ -1486,6 +1668,12 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 		// depth passes the cut at shading.c:120
 		if (mat->reflect > 0.0f && (int)depth + 1 <= sc.max_reflections)
 			n_children = (mat->glossiness <= 0.0f || depth > 1) ? 1 : sc.reflection_samples;
+	}
+	if (TRANSPOSE) {
+		// every lane of the wave takes part, whether it holds a hit or not
+		const c3 lit_total = lights_transposed(io, active && hit, position, normal, cam_dir, material, key, stack, n_shadow);
+		if (active && hit)
+			total = lit_total;
 	}
 
 	// Compact the spawning lanes: one slot reservation per wave.
@@ -1649,6 +1837,9 @@ DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_t
 #ifndef RT_BOUNCE_PACKET
 #define RT_BOUNCE_PACKET 0
 #endif
+#ifndef RT_BOUNCE_TRANSPOSE
+#define RT_BOUNCE_TRANSPOSE 1
+#endif
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES)
 k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
 		int rng_mode, uint32_t seed, const int32_t *glibc_table, long long *accum, float *direct_out,
@@ -1680,7 +1871,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		ray = camera_ray(sc, px, py, offx, offy);
 	}
 	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_LISTS * RT_SHAFT_CAP];
-	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters, s_shaft[threadIdx.x >> 6] };
+	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters, s_shaft[threadIdx.x >> 6], nullptr, nullptr };
 	rtamd_hit_record *rec = nullptr;
 	if (hits && active) {
 		// window-local record index
@@ -1701,7 +1892,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		sample_offsets(sc, rng_mode, glibc_table, seed, qx, qy, qk, qkey, ox, oy);
 		return camera_ray(sc, qx, qy, ox, oy).d;
 	};
-	c3 total = shade_vertex<true>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env, ray_again);
+	c3 total = shade_vertex<true, false>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env, ray_again);
 	{
 		// the pixel mapping again, rather than five registers kept through the kernel
 		unsigned tid = threadIdx.x;
@@ -1824,7 +2015,10 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 	// every lane of a wave runs the same number of iterations (the wave-level
 	// compaction inside shade_vertex needs all 64 lanes present)
 	const unsigned rounds = (count + stride - 1) / stride;
-	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, shaft_lists };
+	__shared__ int4 s_wave_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
+	__shared__ float s_wave_sum[RT_BLOCK / 64][384];
+	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, shaft_lists,
+		reinterpret_cast<int *>(s_wave_stack + (threadIdx.x >> 6) * RT_MAX_STACK), s_wave_sum[threadIdx.x >> 6] };
 	unsigned n_shadow = 0, n_env = 0, n_rays = 0;
 	for (unsigned round = 0; round < rounds; round++) {
 		unsigned idx = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1849,7 +2043,7 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 			const double *dq = queue_in[i].d;
 			return d3{ dq[0], dq[1], dq[2] };
 		};
-		c3 total = shade_vertex<RT_BOUNCE_PACKET != 0>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env, ray_again);
+		c3 total = shade_vertex<RT_BOUNCE_PACKET != 0, RT_BOUNCE_TRANSPOSE != 0>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env, ray_again);
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}
