@@ -437,7 +437,7 @@ DEV d3 primitive_normal(CSurface &s, d3 o, d3 d, float t, int ncode)
 
 // ray.c:327-358.  Vertices are float-valued (objreader narrows every coordinate
 // to float, mesh.c:93-95), so they are stored as floats and widened here.
-DEV bool triangle_intersect(d3 o, d3 d, const float4 &p0, const float4 &p1, const float4 &p2,
+DEV bool triangle_intersect(d3 o, d3 d, const float4 &p0, const float4 &p1, const float4 &p2, float wlo, float whi,
 		float &aa, float &bb, float &cc, double &t)
 {
 	d3 u = { (double)p0.x, (double)p0.y, (double)p0.z };
@@ -461,10 +461,14 @@ DEV bool triangle_intersect(d3 o, d3 d, const float4 &p0, const float4 &p1, cons
 		return false;
 	d3 qvec = vcross(tvec, edge1);
 	const double x2 = vdot(d, qvec);
+	const double x3 = vdot(edge2, qvec);
 	const float c_approx = (float)x2 * rdet;
 	const float s_approx = c_approx + b_approx;
+	// the caller's window for t, widened (see window_lo / window_hi)
+	const float t_approx = (float)x3 * rdet;
 	if ((c_approx < -1e-30f && c_approx > -big) ||
-			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big))
+			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big) ||
+			(t_approx < wlo && t_approx > -big) || (t_approx > whi && t_approx < big))
 		return false;
 	bb = (float)(x1 / (double)det);
 	if ((double)bb < 0.0 || (double)bb > 1.0)
@@ -473,7 +477,7 @@ DEV bool triangle_intersect(d3 o, d3 d, const float4 &p0, const float4 &p1, cons
 	if ((double)cc < 0.0 || (double)(cc + bb) > 1.0)
 		return false;
 	aa = (float)(1.0 - (double)bb - (double)cc);
-	t = vdot(edge2, qvec) / (double)det;
+	t = x3 / (double)det;
 	return true;
 }
 
@@ -571,7 +575,14 @@ typedef unsigned long long u64;
 // evaluated by every lane and decided wave-wide, so the common case (no lane
 // can hit) costs no divergent branch; the exact quotients are computed only by
 // lanes that may hit.  `act` says whether this lane's ray takes part.
-DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool act,
+// [wlo, whi] is the caller's acceptance window for t, widened by 2^-18 (window_lo /
+// window_hi): a triangle whose approximate t lies outside cannot be accepted, in
+// particular the triangle a shadow ray starts on (t = -1e-4 cos), which would
+// otherwise reach the exact quotients on every ray.
+DEV float window_lo(float tlo) { return tlo - __builtin_fabsf(tlo) * 3.814697265625e-06f - 1e-30f; }
+DEV float window_hi(float thi) { return thi + __builtin_fabsf(thi) * 3.814697265625e-06f + 1e-30f; }
+
+DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool act, float wlo, float whi,
 		float &aa, float &bb, float &cc, double &t)
 {
 	d3 pvec = vcross(d, edge2);
@@ -587,10 +598,14 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 	RT_EV(EV_TRI_STAGE2);
 	d3 qvec = vcross(tvec, edge1);
 	const double x2 = vdot(d, qvec);
+	const double x3 = vdot(edge2, qvec);
 	const float c_approx = (float)x2 * rdet;
 	const float s_approx = c_approx + b_approx;
+	// relative error of t_approx below 2^-22 whenever it is finite: far inside the window's margin
+	const float t_approx = (float)x3 * rdet;
 	maybe = maybe && !((c_approx < -1e-30f && c_approx > -big) ||
-			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big));
+			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big) ||
+			(t_approx < wlo && t_approx > -big) || (t_approx > whi && t_approx < big));
 	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
 		return false;
 	RT_EV(EV_TRI_EXACT);
@@ -601,7 +616,7 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 			cc = (float)(x2 / (double)det);
 			if (!((double)cc < 0.0 || (double)(cc + bb) > 1.0)) {
 				aa = (float)(1.0 - (double)bb - (double)cc);
-				t = vdot(edge2, qvec) / (double)det;
+				t = x3 / (double)det;
 				ok = true;
 			}
 		}
@@ -624,6 +639,7 @@ DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear,
 	const float4 *tris = reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first);
 	const PacketRay br = make_packet_ray(o, d, tnear, tfar);
 	const double dnear = (double)tnear, dfar = (double)tfar;
+	const float wlo = window_lo(tnear);
 	bool found = false;
 	best_t = __builtin_huge_val();
 	best_orig = -1;
@@ -666,7 +682,7 @@ DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear,
 				float aa, bb, cc;
 				double t;
 				RT_STAT(atomicAdd(&g_stat_tris, 1ull));
-				if (!triangle_intersect(o, d, p0, p1, p2, aa, bb, cc, t))
+				if (!triangle_intersect(o, d, p0, p1, p2, wlo, window_hi(limit), aa, bb, cc, t))
 					continue;
 				int orig = as_i(p0.w);
 				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
@@ -703,6 +719,7 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 	const CONSTAS DevTriEdges *edges = in_const(sc.edges) + mesh.tri_first;
 	const PacketRay pr = make_packet_ray(o, d, tnear, tfar);
 	const double dnear = (double)tnear, dfar = (double)tfar;
+	const float wlo = window_lo(tnear);
 	bool found = false;
 	best_t = __builtin_huge_val();
 	best_orig = -1;
@@ -765,7 +782,8 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 				double t;
 				RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
 				const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
-				const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, aa, bb, cc, t);
+				const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act,
+						wlo, window_hi(limit), aa, bb, cc, t);
 				int orig = te.orig;
 				if (ok && t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
 					best_t = t;
@@ -999,6 +1017,7 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 	const CONSTAS DevTriEdges *edges = in_const(sc.edges) + mesh.tri_first;
 	const PacketRay pr = make_packet_ray(o, d, tnear, tfar);
 	const double dnear = (double)tnear, dfar = (double)tfar;
+	const float wlo = window_lo(tnear), whi = window_hi(tfar);
 	bool found = false;
 	for (int c = 0; c < count; c++) {
 		const ShaftEntry e = list[c];
@@ -1016,7 +1035,7 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 			double t;
 			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
 			const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
-			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, aa, bb, cc, t);
+			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, wlo, whi, aa, bb, cc, t);
 			if (ok && t >= dnear && t <= dfar)
 				found = true;
 			actm &= ~__builtin_amdgcn_ballot_w64(found);
