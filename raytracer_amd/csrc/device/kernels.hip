@@ -1868,7 +1868,8 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	// one traversal stack per wave (packet traversal)
 	__shared__ int4 s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
 	__shared__ __attribute__((aligned(16))) float s_sum[RT_BLOCK / 64][3 * 64];
-	int *stack = reinterpret_cast<int *>(s_stack + (threadIdx.x >> 6) * RT_MAX_STACK);
+	const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar register
+	int *stack = reinterpret_cast<int *>(s_stack + wave * RT_MAX_STACK);
 #ifdef RT_TIMING
 	if ((threadIdx.x & 63) < TM_COUNT)
 		s_timing[threadIdx.x >> 6][threadIdx.x & 63] = 0;
@@ -1890,7 +1891,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		ray = camera_ray(sc, px, py, offx, offy);
 	}
 	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_LISTS * RT_SHAFT_CAP];
-	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters, s_shaft[threadIdx.x >> 6], nullptr, nullptr };
+	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters, s_shaft[wave], nullptr, nullptr };
 	rtamd_hit_record *rec = nullptr;
 	if (hits && active) {
 		// window-local record index
@@ -1912,12 +1913,15 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		return camera_ray(sc, qx, qy, ox, oy).d;
 	};
 	c3 total = shade_vertex<true, false>(io, ray, 0, key, weight, slot, active, stack, rec, n_shadow, n_env, ray_again);
+	// the pixel mapping again, rather than five registers kept through the kernel
+	int tx = 0, ty = 0, tk = 0;
+	uint32_t tslot = 0;
+	bool tactive;
 	{
-		// the pixel mapping again, rather than five registers kept through the kernel
 		unsigned tid = threadIdx.x;
 		asm volatile("" : "+v"(tid));
 		const unsigned long long l2 = (unsigned long long)blockIdx.x * RT_BLOCK + tid;
-		active = l2 < sample_count && sample_to_pixel(tm, sc.spp, sample_first + l2, px, py, k, slot);
+		tactive = l2 < sample_count && sample_to_pixel(tm, sc.spp, sample_first + l2, tx, ty, tk, tslot);
 	}
 
 	TM_BEGIN(t_tail);
@@ -1930,7 +1934,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		float ar = total.r, ag = total.g, ab = total.b;
 		if (spp % 4 == 0) {
 			// through LDS: one lane per (pixel, channel) walks its run of samples
-			float *sw = s_sum[threadIdx.x >> 6];
+			float *sw = s_sum[wave];
 			sw[lane] = total.r; sw[64 + lane] = total.g; sw[128 + lane] = total.b;
 			const unsigned ppw = 64 / spp;
 			if (lane < 3 * ppw) {
@@ -1953,7 +1957,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 				ab += __shfl(total.b, (int)(base + j), 64);
 			}
 		}
-		if (active && lane == base) {
+		if (tactive && lane == base) {
 			if (direct_out) {
 				// no other contribution can arrive: write the pixel (raytracer.c:46,81)
 				if (sc.antialiasing) {
@@ -1961,18 +1965,18 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 					ar = s * ar; ag = s * ag; ab = s * ab;
 				}
 				float4 out = { ar, ag, ab, 0.0f };
-				reinterpret_cast<float4 *>(direct_out)[(unsigned long long)sc.width * py + px] = out;
+				reinterpret_cast<float4 *>(direct_out)[(unsigned long long)sc.width * ty + tx] = out;
 			} else {
-				accumulate(accum, slot, { ar, ag, ab });
+				accumulate(accum, tslot, { ar, ag, ab });
 			}
 		}
 	} else {
 		// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
 		// not depend on the order in which lanes, waves or later bounces arrive.
-		long long r = active ? to_fixed(total.r) : 0, g = active ? to_fixed(total.g) : 0,
-		     b = active ? to_fixed(total.b) : 0;
+		long long r = tactive ? to_fixed(total.r) : 0, g = tactive ? to_fixed(total.g) : 0,
+		     b = tactive ? to_fixed(total.b) : 0;
 		// segmented reduction over runs of lanes that share a pixel (runs are contiguous)
-		uint32_t seg = active ? slot : 0xffffffffu;
+		uint32_t seg = tactive ? tslot : 0xffffffffu;
 		for (int off = 1; off < 64; off <<= 1) {
 			uint32_t oseg = __shfl_down(seg, off, 64);
 			long long orr = __shfl_down(r, off, 64), og = __shfl_down(g, off, 64), ob = __shfl_down(b, off, 64);
@@ -1983,15 +1987,15 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 			}
 		}
 		uint32_t prev = __shfl_up(seg, 1, 64);
-		bool head = active && (lane == 0 || prev != seg);
+		bool head = tactive && (lane == 0 || prev != seg);
 		if (head) {
-			unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
+			unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * tslot);
 			if (r) atomicAdd(p + 0, (unsigned long long)r);
 			if (g) atomicAdd(p + 1, (unsigned long long)g);
 			if (b) atomicAdd(p + 2, (unsigned long long)b);
 		}
 	}
-	const u64 active_lanes = __builtin_amdgcn_ballot_w64(active), env_lanes = __builtin_amdgcn_ballot_w64(n_env != 0);
+	const u64 active_lanes = __builtin_amdgcn_ballot_w64(tactive), env_lanes = __builtin_amdgcn_ballot_w64(n_env != 0);
 	if (lane == 0) {
 		if (active_lanes) atomicAdd(&counters->rays_primary, (unsigned long long)__builtin_popcountll(active_lanes));
 		if (env_lanes) atomicAdd(&counters->env_lookups, (unsigned long long)__builtin_popcountll(env_lanes));
