@@ -868,7 +868,8 @@ struct ShaftTest {
 
 struct ShaftState {
 	u64 cull;            // bit si: no ray of this wave and light can pass the surface's box
-	unsigned counts;     // 8 bits per listed mesh: number of leaves, 0xff = no list
+	unsigned counts;     // 8 bits per list: number of leaves, 0xff = no list
+	unsigned surfaces;   // 8 bits per list: the surface it belongs to, 0xff = none
 	const ShaftEntry *lists;
 };
 
@@ -1058,6 +1059,7 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 	ShaftState ss;
 	ss.cull = 0;
 	ss.counts = 0xffffffffu;
+	ss.surfaces = 0xffffffffu;
 	ss.lists = lists;
 	// alpha = p/n + drand() reaches (n-1)/n + 1 (shading.c:30-31)
 	const float amax = ((float)(n - 1) / (float)n + 1.0f) * 1.000001f;
@@ -1099,7 +1101,7 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 			RT_STAT(if (counter) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 2], 1ull));
 			continue;
 		}
-		if (!is_mesh || my_slot >= RT_SHAFT_LISTS || !s.affine) {
+		if (!is_mesh || my_slot >= RT_SHAFT_LISTS || !s.affine || si >= 255) {
 			RT_STAT(if (counter) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 3], 1ull));
 			continue;
 		}
@@ -1109,8 +1111,10 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 		const ShaftTest model = shaft_make(cm0, rm0, cm1, rm1);
 		const int n_leaves = shaft_collect(sc, in_const(sc.meshes)[s.mesh], model, wstack, lists + my_slot * RT_SHAFT_CAP);
 		RT_STAT(if (counter) atomicAdd(&g_stat_shaft[n_leaves >= 0 ? n_leaves : RT_SHAFT_CAP + 1], 1ull));
-		if (n_leaves >= 0)
+		if (n_leaves >= 0) {
 			ss.counts = (ss.counts & ~(0xffu << (8 * my_slot))) | ((unsigned)n_leaves << (8 * my_slot));
+			ss.surfaces = (ss.surfaces & ~(0xffu << (8 * my_slot))) | ((unsigned)si << (8 * my_slot));
+		}
 	}
 	return ss;
 }
@@ -1122,6 +1126,7 @@ DEV ShaftState shaft_none()
 	ShaftState ss;
 	ss.cull = 0;
 	ss.counts = 0xffffffffu;
+	ss.surfaces = 0xffffffffu;
 	ss.lists = nullptr;
 	return ss;
 }
@@ -1133,20 +1138,25 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 	best.surface = -1;
 	best.tri = -1;
 	best.t = __builtin_huge_valf();
-	int mesh_slot = 0;
-	for (int si = 0; si < sc.num_surfaces; si++) {
+	// surfaces the light's shaft misses are stepped over without being looked at
+	const bool masked = ANYHIT && PACKET;
+	const u64 wanted = ~shaft.cull;
+	auto next_wanted = [&](int i) {
+		if (masked && i < 64) {
+			const u64 rest = wanted >> i;
+			return rest ? i + (int)__builtin_ctzll(rest) : 64;
+		}
+		return i;
+	};
+	for (int si = next_wanted(0); si < sc.num_surfaces; si = next_wanted(si + 1)) {
 		CSurface &s = in_const(sc.surfaces)[si];
-		int shaft_count = 0xff;
-		if (ANYHIT && PACKET) {
-			if (s.shape_type == RTAMD_SHAPE_MESH) {
-				if (mesh_slot < RT_SHAFT_LISTS)
-					shaft_count = (int)((shaft.counts >> (8 * mesh_slot)) & 0xffu);
-				mesh_slot++;
-			}
-			if (si < 64 && ((shaft.cull >> si) & 1)) {
-				RT_EV(EV_CULLED);
-				continue;
-			}
+		int shaft_count = 0xff, shaft_slot = 0;
+		if (masked) {
+			for (int k = 0; k < RT_SHAFT_LISTS; k++)
+				if ((int)((shaft.surfaces >> (8 * k)) & 0xffu) == si) {
+					shaft_count = (int)((shaft.counts >> (8 * k)) & 0xffu);
+					shaft_slot = k;
+				}
 		}
 		RT_EV(ANYHIT ? EV_BBOX_SHADOW : EV_BBOX_PRIMARY);
 		float bnear, bfar;
@@ -1180,7 +1190,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 				RT_EV(EV_MESH_LIST_SHADOW);
 				// every listed leaf's triangles; a hit's t lies in [bnear, bfar]
 				hits = mesh_candidates_anyhit(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar,
-						shaft.lists + (mesh_slot - 1) * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
+						shaft.lists + shaft_slot * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
 				t = (double)bnear;
 			} else if (PACKET) {
 				RT_EV(ANYHIT ? EV_MESH_WALK_SHADOW : EV_MESH_WALK_PRIMARY);
