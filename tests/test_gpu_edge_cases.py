@@ -94,6 +94,18 @@ def test_sample_counts_that_do_not_fill_or_divide_a_wave(render, tmp_path, aa, s
     check(render, write_scene(tmp_path, f"spp-{aa}-{ss}", body, w=24, h=16, aa=aa, ss=ss))
 
 
+@pytest.mark.parametrize("ss", [3, 5, 6, 8, 9])
+def test_bounced_hits_with_every_light_sample_layout(render, tmp_path, ss):
+    """Reflective surfaces under area lights: the bounce kernel lays the n x n light
+    samples of its hit points out over the lanes of a wave in runs (n x n < 64),
+    in chunks of 64 (n x n >= 64) or keeps them per lane (short runs)."""
+    body = FLOOR.replace("grey", "shiny") + (
+        '<Translate vector="0 1.2 0"><Rotate axis="1 0 0" angle="30"><Shape geometry="torus" material="shiny" />'
+        '</Rotate></Translate>\n<Translate vector="2 0.5 1"><Shape geometry="cube" material="grey" /></Translate>\n')
+    st = check(render, write_scene(tmp_path, f"bounce-{ss}", body, w=20, h=12, aa=2, ss=ss))
+    assert st.rays_secondary > 0
+
+
 def test_more_meshes_than_shaft_lists(render, tmp_path):
     body = FLOOR
     for i in range(7):
