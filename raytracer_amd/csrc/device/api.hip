@@ -487,8 +487,11 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		rtamd_set_error("too many pixels per call");
 		return RTAMD_ERR_LIMIT;
 	}
+	// Without reflections, and with all samples of a pixel inside one wave, the
+	// primary kernel writes finished pixels itself: no accumulators, no resolve.
+	const bool direct = !dev.any_reflective && 64 % dev.spp == 0;
 	// work buffers
-	if (sc->accum_slots < pixels) {
+	if (!direct && sc->accum_slots < pixels) {
 		if (sc->d_accum) {
 			HIP_TRY(hipStreamSynchronize(stream));
 			(void)hipFree(sc->d_accum);
@@ -543,9 +546,6 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		HIP_TRY(hipEventCreate(&ev[1]));
 		HIP_TRY(hipEventRecord(ev[0], stream));
 	}
-	// Without reflections, and with all samples of a pixel inside one wave, the
-	// primary kernel writes finished pixels itself: no accumulators, no resolve.
-	const bool direct = !dev.any_reflective && 64 % dev.spp == 0;
 	if (!direct)
 		HIP_TRY(hipMemsetAsync(sc->d_accum, 0, pixels * 3 * sizeof(long long), stream));
 	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DevCounters), stream));
