@@ -226,6 +226,11 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 	int *stack = s_stack + threadIdx.x;
 	ShaftEntry *shaft_lists = nullptr;
 #endif
+#ifdef RT_TIMING
+	if ((threadIdx.x & 63) < TM_COUNT)
+		s_timing[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+#endif
+	TM_BEGIN(t_kernel);
 	unsigned count = *queue_in_count;
 	if (count > queue_capacity)
 		count = queue_capacity;
@@ -270,6 +275,11 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 	wave_count_add(&counters->rays_secondary, n_rays);
 	wave_count_add(&counters->rays_shadow, n_shadow);
 	wave_count_add(&counters->env_lookups, n_env);
+	TM_END(TM_KERNEL, t_kernel);
+#ifdef RT_TIMING
+	if ((threadIdx.x & 63) < TM_COUNT)
+		atomicAdd(&g_timing_bounce[threadIdx.x & 63], s_timing[threadIdx.x >> 6][threadIdx.x & 63]);
+#endif
 }
 
 #if defined(RT_TRAVERSAL_STATS) || defined(RT_TIMING)
@@ -293,8 +303,9 @@ __global__ void k_collect_stats(DevCounters *counters)
 #endif
 #ifdef RT_TIMING
 	for (int i = 0; i < TM_COUNT; i++) {
-		printf("timing %d %llu\n", i, g_timing[i]);
+		printf("timing %d %llu bounce %llu\n", i, g_timing[i], g_timing_bounce[i]);
 		g_timing[i] = 0;
+		g_timing_bounce[i] = 0;
 	}
 #endif
 }

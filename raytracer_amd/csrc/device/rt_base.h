@@ -66,7 +66,7 @@ enum { TM_KERNEL, TM_SETUP, TM_TRACE_PRIMARY, TM_FINISH, TM_LIGHT_SETUP, TM_TRAC
 	TM_SPAWN, TM_TAIL, TM_SHAFT, TM_BOUNDS,
 	TM_IN_BBOX, TM_IN_XFORM, TM_IN_PRIM, TM_IN_MESH_SETUP, TM_IN_NODES, TM_IN_LEAVES, TM_IN_POP, TM_IN_SELECT,
 	TM_SHADOW_OFFSET = 8, TM_COUNT = TM_IN_SELECT + 1 + TM_SHADOW_OFFSET };
-__device__ unsigned long long g_timing[TM_COUNT];
+__device__ unsigned long long g_timing[TM_COUNT], g_timing_bounce[TM_COUNT];
 __shared__ unsigned long long s_timing[RT_BLOCK / 64][TM_COUNT];
 DEV unsigned long long tm_now() { return __builtin_readcyclecounter(); }
 DEV void tm_add(int cat, unsigned long long t0)

@@ -195,6 +195,7 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 	c3 total = { 0.0f, 0.0f, 0.0f };
 	const u64 lit_lanes = __builtin_amdgcn_ballot_w64(lit);
 	const int hits = __builtin_popcountll(lit_lanes);
+	TM_BEGIN(t_all);
 	for (int li = 0; li < sc.num_lights; li++) {
 		CLight &light = in_const(sc.lights)[li];
 		const bool area = light.type == RTAMD_LIGHT_AREA;
@@ -245,11 +246,19 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 				if (valid) {
 					CMaterial &mat = in_const(sc.materials)[hm];
 					d3 light_dir;
+					TM_BEGIN(t_gen);
 					const Ray shadow = shadow_ray_towards(hp, light_sample_point(sc, light, area, n, li, hk, j), light_dir);
+					TM_END(TM_LIGHT_SETUP, t_gen);
 					Best dummy;
-					if (!trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none()))
+					TM_BEGIN(t_tr);
+					const bool occluded = trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none());
+					TM_END(TM_TRACE_SHADOW, t_tr);
+					TM_BEGIN(t_sh);
+					if (!occluded)
 						c = cadd(diff_colour(light, mat, light_dir, hn), spec_colour(light, mat, hc, light_dir, hn));
+					TM_END(TM_SHADE, t_sh);
 				}
+				TM_BEGIN(t_sum);
 				// per run and channel: ((0 + c_0) + c_1) + ... in sample order (shading.c:18-54;
 				// an occluded sample adds +0, which leaves the non-negative sum unchanged)
 				sum[lane] = c.r; sum[64 + lane] = c.g; sum[128 + lane] = c.b;
@@ -270,6 +279,7 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 						n_shadow += (unsigned)m;
 					}
 				}
+				TM_END(TM_TAIL, t_sum);
 			}
 			continue;
 		}
@@ -308,6 +318,7 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 			}
 		}
 	}
+	TM_END(TM_SHAFT, t_all);
 	return total;
 }
 
