@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -52,6 +53,10 @@ struct rtamd_scene {
 	unsigned queue_capacity = 0;
 	unsigned *d_qcount = nullptr;
 	DevCounters *d_counters = nullptr;
+	// coherent bounce pass (see kernels.hip): per-entry scratch sized like the queues
+	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+	unsigned bounce_capacity = 0;
+	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 };
 
 namespace {
@@ -118,6 +123,17 @@ extern "C" const char *rtamd_version(void)
 	return "rtamd 0.1 (gfx950)";
 }
 
+static void free_bounce_work(rtamd_scene *sc)
+{
+	BounceWork &w = sc->bounce;
+	void *ptrs[] = { w.hits, w.bins, w.perm, w.hist, w.sums, w.bounds };
+	for (void *p : ptrs)
+		if (p)
+			(void)hipFree(p);
+	w = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.bits };
+	sc->bounce_capacity = 0;
+}
+
 extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 {
 	if (!sc)
@@ -130,6 +146,7 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 	if (sc->d_queue[1]) (void)hipFree(sc->d_queue[1]);
 	if (sc->d_qcount) (void)hipFree(sc->d_qcount);
 	if (sc->d_counters) (void)hipFree(sc->d_counters);
+	free_bounce_work(sc);
 	delete sc;
 	return 0;
 }
@@ -239,6 +256,18 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 			if (m.glossiness > 0.0f)
 				any_glossy = true;
 		}
+	}
+	{
+		// The coherent bounce pass pays when a bounced hit sends many shadow rays
+		// (area lights); RTAMD_BOUNCE=sorted|legacy overrides the choice, and
+		// RTAMD_SORT_BITS the grid resolution (bits per axis).
+		const char *mode = getenv("RTAMD_BOUNCE");
+		sc->sorted_bounce = any_area && h.shadow_samples >= 2;
+		if (mode && !strcmp(mode, "sorted")) sc->sorted_bounce = true;
+		if (mode && !strcmp(mode, "legacy")) sc->sorted_bounce = false;
+		const char *bits = getenv("RTAMD_SORT_BITS");
+		int b = bits ? atoi(bits) : 7;
+		sc->bounce.bits = b < 1 ? 1 : (b > RT_SORT_BITS_MAX ? RT_SORT_BITS_MAX : b);
 	}
 	sc->fixed_consumption = !any_area && !any_glossy;
 	sc->glossy = any_glossy;
@@ -530,6 +559,20 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			}
 			sc->queue_capacity = cap;
 		}
+		if (sc->sorted_bounce && sc->bounce_capacity < sc->queue_capacity) {
+			HIP_TRY(hipStreamSynchronize(stream));
+			free_bounce_work(sc);
+			const size_t n = sc->queue_capacity;
+			const size_t n_bins = ((size_t)1 << (3 * sc->bounce.bits)) + 1;
+			void *ptr = nullptr;
+			HIP_TRY(hipMalloc(&ptr, n * sizeof(BounceHit)));   sc->bounce.hits = static_cast<BounceHit *>(ptr);
+			HIP_TRY(hipMalloc(&ptr, n * sizeof(BounceBin)));   sc->bounce.bins = static_cast<BounceBin *>(ptr);
+			HIP_TRY(hipMalloc(&ptr, n * sizeof(unsigned)));    sc->bounce.perm = static_cast<unsigned *>(ptr);
+			HIP_TRY(hipMalloc(&ptr, n_bins * sizeof(unsigned)));  sc->bounce.hist = static_cast<unsigned *>(ptr);
+			HIP_TRY(hipMalloc(&ptr, 4096 * sizeof(unsigned))); sc->bounce.sums = static_cast<unsigned *>(ptr);
+			HIP_TRY(hipMalloc(&ptr, 8 * sizeof(unsigned)));    sc->bounce.bounds = static_cast<unsigned *>(ptr);
+			sc->bounce_capacity = sc->queue_capacity;
+		}
 		chunk = sc->queue_capacity / fan;
 		chunk -= chunk % RT_BLOCK;
 		if (chunk < RT_BLOCK) {
@@ -577,9 +620,14 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		launches_primary++;
 		for (int level = 1; level <= levels; level++) {
 			// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
-			HIP_TRY(rt_launch_bounce(dev, sc->d_queue[(level - 1) & 1], sc->d_qcount + (level - 1),
-					sc->queue_capacity, sc->d_accum, level < levels ? sc->d_queue[level & 1] : nullptr,
-					sc->d_qcount + level, sc->d_counters, bounce_grid, stream));
+			if (sc->sorted_bounce)
+				HIP_TRY(rt_launch_bounce_sorted(dev, sc->d_queue[(level - 1) & 1], sc->d_qcount + (level - 1),
+						sc->queue_capacity, sc->d_accum, level < levels ? sc->d_queue[level & 1] : nullptr,
+						sc->d_qcount + level, sc->d_counters, sc->bounce, bounce_grid, stream));
+			else
+				HIP_TRY(rt_launch_bounce(dev, sc->d_queue[(level - 1) & 1], sc->d_qcount + (level - 1),
+						sc->queue_capacity, sc->d_accum, level < levels ? sc->d_queue[level & 1] : nullptr,
+						sc->d_qcount + level, sc->d_counters, bounce_grid, stream));
 			launches_bounce++;
 		}
 	}

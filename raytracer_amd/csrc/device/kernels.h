@@ -15,6 +15,21 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
 		DevCounters *counters, unsigned grid_blocks, hipStream_t stream);
+/* Scratch of one bounce level of the coherent pass: per queue entry the nearest
+ * hit, its bin and the sorted order; the bin histogram ((2^bits)^3 + 1 entries,
+ * scanned in place), the per-segment sums of the scan, the hit-point bounds. */
+struct BounceWork {
+	BounceHit *hits;
+	BounceBin *bins;
+	unsigned *perm;
+	unsigned *hist;
+	unsigned *sums;
+	unsigned *bounds;
+	int bits;
+};
+hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
+		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
+		DevCounters *counters, const BounceWork &work, unsigned grid_blocks, hipStream_t stream);
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
 		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
 		hipStream_t stream);

@@ -48,9 +48,10 @@ __device__ unsigned long long g_stat_nodes, g_stat_tris;
 // [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
 __device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
 // wave-level event counts: see the EV_ names
-__device__ unsigned long long g_stat_ev[16];
+__device__ unsigned long long g_stat_ev[32];
 enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
-	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS, EV_CULLED };
+	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS, EV_CULLED,
+	EV_BOX_SIZE0 = 16 /* .. 31: largest extent of a wave's hit-point box, 0.001 * 2^k */ };
 #define RT_EV(e) do { if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], 1ull); } while (0)
 #else
 #define RT_EV(e) do { } while (0)

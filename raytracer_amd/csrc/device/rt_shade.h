@@ -322,35 +322,19 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 	return total;
 }
 
-// ---- shading of one path vertex: shading.c:114-141 without the recursion ------
-//
-// Returns the radiance this vertex contributes directly (environment, or the sum
-// of the light loops) and pushes reflection / glossy children into the bounce
-// queue with their throughput weight.
-
-
 // `ray_again` returns the incoming direction once more (recomputed or re-read by
 // the caller): it is needed again only when a reflection is spawned, after all the
 // shadow rays, and is not worth six registers until then.
+//
+// shade_hit is the part of a path vertex after its nearest hit is known: the light
+// loops and the children.  `lit` = this lane holds a hit; every lane of the wave
+// must call it (wave-wide compaction, shafts and transposed loops need all 64).
 template <bool PACKET, bool TRANSPOSE, typename RayAgain>
-DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t key, c3 weight,
-		uint32_t slot, bool active, int *stack, rtamd_hit_record *rec,
-		unsigned &n_shadow, unsigned &n_env, RayAgain ray_again)
+DEV c3 shade_hit(const ShadeIO &io, bool lit, int surface, d3 position, d3 normal, d3 ray_d, uint32_t depth,
+		uint32_t key, c3 weight, uint32_t slot, int *stack, unsigned &n_shadow, RayAgain ray_again)
 {
 	const DevScene &sc = *io.sc;
 	c3 total = { 0.0f, 0.0f, 0.0f };
-	Best best;
-	bool hit = false;
-	d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
-	if (active) {
-		TM_BEGIN(t_trace);
-		hit = trace<false, PACKET>(sc, ray, stack, best, shaft_none());
-		TM_END(TM_TRACE_PRIMARY, t_trace);
-		TM_BEGIN(t_finish);
-		if (hit)
-			finish_hit(sc, ray, best, position, normal);
-		TM_END(TM_FINISH, t_finish);
-	}
 	// bounds of the wave's hit points (origins of its shadow rays), rounded outwards
 	float olo[3] = { 0, 0, 0 }, ohi[3] = { 0, 0, 0 };
 	const bool shafts = RT_SHAFT && PACKET && io.shaft_lists && sc.any_area_light;
@@ -361,7 +345,7 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 		for (int a = 0; a < 3; a++) {
 			const float f = (float)pv[a];
 			const float w = __builtin_fabsf(f) * 1.1920929e-7f + 1e-37f;
-			float lo = hit ? f - w : inf, hi = hit ? f + w : -inf;
+			float lo = lit ? f - w : inf, hi = lit ? f + w : -inf;
 			for (int off = 32; off > 0; off >>= 1) {
 				lo = __builtin_fminf(lo, __shfl_xor(lo, off, 64));
 				hi = __builtin_fmaxf(hi, __shfl_xor(hi, off, 64));
@@ -371,38 +355,24 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 		}
 	}
 	TM_END(TM_BOUNDS, t_bounds);
-	if (rec && active) {
-		rtamd_hit_record r;
-		r.surface = hit ? best.surface : -1;
-		r.triangle = -1;
-		if (hit && best.ncode == NC_MESH) {
-			CMesh &mesh = in_const(sc.meshes)[in_const(sc.surfaces)[best.surface].mesh];
-			r.triangle = as_i(reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first)[3 * best.tri].w);
-		}
-		r.t = hit ? best.t : 0.0f;
-		r.pad = 0.0f;
-		r.position[0] = position.x; r.position[1] = position.y; r.position[2] = position.z;
-		r.normal[0] = normal.x; r.normal[1] = normal.y; r.normal[2] = normal.z;
-		*rec = r;
+#ifdef RT_TRAVERSAL_STATS
+	if (shafts && depth > 0 && ohi[0] >= olo[0]) {
+		const float ext = __builtin_fmaxf(__builtin_fmaxf(ohi[0] - olo[0], ohi[1] - olo[1]), ohi[2] - olo[2]);
+		int k = 0;
+		while (k < 15 && ext > 0.001f * (float)(2 << k))
+			k++;
+		RT_EV(EV_BOX_SIZE0 + k);
 	}
+#endif
 
 	int n_children = 0;
 	CMaterial *mat = nullptr;
 	d3 cam_dir = { 0, 0, 0 };
 	int material = 0;
-	if (active && !hit) {
-		// shading.c:123-129
-		if (sc.has_cubemap) {
-			TM_BEGIN(t_env);
-			total = cubemap_colour(sc, ray.d);
-			TM_END(TM_ENV, t_env);
-			n_env++;
-		} else
-			total = lc3(sc.background);
-	} else if (active) {
-		material = in_const(sc.surfaces)[best.surface].material;
+	if (lit) {
+		material = in_const(sc.surfaces)[surface].material;
 		mat = &in_const(sc.materials)[material];
-		cam_dir = vnorm(vscale(-1, ray.d));                          // shading.c:118
+		cam_dir = vnorm(vscale(-1, ray_d));                          // shading.c:118
 		// shading.c:133-135 -> hit_light_colour, shading.c:7-58
 		for (int li = 0; !TRANSPOSE && li < sc.num_lights; li++) {
 			CLight &light = in_const(sc.lights)[li];
@@ -450,8 +420,8 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	}
 	if (TRANSPOSE) {
 		// every lane of the wave takes part, whether it holds a hit or not
-		const c3 lit_total = lights_transposed(io, active && hit, position, normal, cam_dir, material, key, stack, n_shadow);
-		if (active && hit)
+		const c3 lit_total = lights_transposed(io, lit, position, normal, cam_dir, material, key, stack, n_shadow);
+		if (lit)
 			total = lit_total;
 	}
 
@@ -476,7 +446,12 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 			unsigned my = base + prefix - want;
 			if (want) {
 				if (my + want > io.queue_capacity) {
+					// The children are dropped and the frame is reported incomplete.  The
+					// consumer reads min(count, capacity) entries: those of this lane's
+					// reserved slots that lie inside the queue are marked unused.
 					atomicAdd(&io.counters->queue_overflow, 1ull);
+					for (unsigned i = my; i < my + want && i < io.queue_capacity; i++)
+						io.queue_out[i].depth = QUEUE_SLOT_UNUSED;
 				} else {
 					// shading.c:81-84
 					const d3 in_dir = ray_again();
@@ -524,4 +499,57 @@ DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t 
 	}
 	TM_END(TM_SPAWN, t_spawn);
 	return total;
+}
+
+// ---- shading of one path vertex: shading.c:114-141 without the recursion ------
+//
+// Returns the radiance this vertex contributes directly (environment, or the sum
+// of the light loops) and pushes reflection / glossy children into the bounce
+// queue with their throughput weight.
+template <bool PACKET, bool TRANSPOSE, typename RayAgain>
+DEV c3 shade_vertex(const ShadeIO &io, const Ray &ray, uint32_t depth, uint32_t key, c3 weight,
+		uint32_t slot, bool active, int *stack, rtamd_hit_record *rec,
+		unsigned &n_shadow, unsigned &n_env, RayAgain ray_again)
+{
+	const DevScene &sc = *io.sc;
+	Best best;
+	bool hit = false;
+	d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
+	if (active) {
+		TM_BEGIN(t_trace);
+		hit = trace<false, PACKET>(sc, ray, stack, best, shaft_none());
+		TM_END(TM_TRACE_PRIMARY, t_trace);
+		TM_BEGIN(t_finish);
+		if (hit)
+			finish_hit(sc, ray, best, position, normal);
+		TM_END(TM_FINISH, t_finish);
+	}
+	if (rec && active) {
+		rtamd_hit_record r;
+		r.surface = hit ? best.surface : -1;
+		r.triangle = -1;
+		if (hit && best.ncode == NC_MESH) {
+			CMesh &mesh = in_const(sc.meshes)[in_const(sc.surfaces)[best.surface].mesh];
+			r.triangle = as_i(reinterpret_cast<const float4 *>(sc.tris + mesh.tri_first)[3 * best.tri].w);
+		}
+		r.t = hit ? best.t : 0.0f;
+		r.pad = 0.0f;
+		r.position[0] = position.x; r.position[1] = position.y; r.position[2] = position.z;
+		r.normal[0] = normal.x; r.normal[1] = normal.y; r.normal[2] = normal.z;
+		*rec = r;
+	}
+	c3 miss_total = { 0.0f, 0.0f, 0.0f };
+	if (active && !hit) {
+		// shading.c:123-129
+		if (sc.has_cubemap) {
+			TM_BEGIN(t_env);
+			miss_total = cubemap_colour(sc, ray.d);
+			TM_END(TM_ENV, t_env);
+			n_env++;
+		} else
+			miss_total = lc3(sc.background);
+	}
+	const c3 lit_total = shade_hit<PACKET, TRANSPOSE>(io, active && hit, best.surface, position, normal, ray.d, depth,
+			key, weight, slot, stack, n_shadow, ray_again);
+	return (active && !hit) ? miss_total : lit_total;
 }

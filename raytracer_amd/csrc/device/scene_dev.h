@@ -117,7 +117,9 @@ struct DevScene {
 	DevCubeFace faces[6];
 };
 
-/* A ray waiting in a bounce queue. */
+/* A ray waiting in a bounce queue.  depth == QUEUE_SLOT_UNUSED marks a slot that
+ * was reserved but never filled (queue overflow): consumers skip it. */
+#define QUEUE_SLOT_UNUSED 0xffffffffu
 struct QueueItem {
 	double o[3];
 	double d[3];
@@ -127,6 +129,26 @@ struct QueueItem {
 	uint32_t depth;
 	uint32_t pad[2];
 };
+
+/* Nearest hit of a queued ray, kept between the trace and the shade kernel of a
+ * bounce pass (the position and normal are rebuilt from it, ray.c:574-576). */
+struct BounceHit {
+	int32_t surface;            /* -1: miss (already shaded) or unused slot */
+	int32_t tri;
+	int32_t ncode;
+	float t;
+	float a, b, c;
+	uint32_t pad;
+};
+
+/* Spatial bin of a bounced hit and its arrival number inside the bin. */
+struct BounceBin {
+	uint32_t key;
+	uint32_t rank;
+};
+
+#define RT_SORT_BITS_MAX 8      /* bits per axis of the hit-point grid: at most 2^24 cells */
+#define RT_SCAN_SEGMENT 8192    /* histogram entries scanned by one workgroup */
 
 struct DevCounters {
 	unsigned long long rays_primary, rays_shadow, rays_secondary, env_lookups;

@@ -47,6 +47,13 @@ SMALL = {
     "prims-aa": dict(width=36, height=24, antialiasing=1, aa_samples=3),
 }
 FULL = ["1-phong", "2-transform", "3-aa", "4-environmentmap", "5-primitives"]
+# the stochastic scenes at 64 samples per pixel (aa_samples = 8), reduced frames:
+# fixture name -> (scene, <Config> overrides)
+SPP64 = {
+    "spp64_6-soft": ("6-soft", dict(width=32, height=16, antialiasing=1, aa_samples=8)),
+    "spp64_8-glossy": ("8-glossy", dict(width=20, height=20, antialiasing=1, aa_samples=8)),
+    "spp64_7-reflections": ("7-reflections", dict(width=20, height=20, antialiasing=1, aa_samples=8)),
+}
 
 
 def scene_path(name):
@@ -87,6 +94,17 @@ def make_small():
             sha_position=sha(hits["position"]), sha_normal=sha(hits["normal"]),
             next_rand=next_rand)
         print("small", name, colour.shape, len(hits), "next_rand", next_rand)
+
+
+def make_spp64():
+    """Reference images (serial rand() stream) of the stochastic scenes at 64 spp."""
+    for fixture, (name, cfg) in SPP64.items():
+        blob = ra.load_sdl(scene_path(name)).with_config(**cfg)
+        with tempfile.TemporaryDirectory() as tmp:
+            _, colour, next_rand = run_ref(REF, blob, tmp, "--no-ppm")
+        np.savez_compressed(os.path.join(HERE, fixture + ".npz"), scene=name, config=json.dumps(cfg),
+                            colour=colour[..., :3].copy(), next_rand=next_rand)
+        print(fixture, colour.shape, "next_rand", next_rand)
 
 
 def make_rays():
@@ -177,6 +195,7 @@ if __name__ == "__main__":
                  "make -C oracle ref")
     make_rand()
     make_small()
+    make_spp64()
     make_rays()
     if "--full" in sys.argv:
         make_full()
