@@ -239,6 +239,10 @@ typedef struct rtamd_render_stats {
  *   stream   : hipStream_t (as void*), NULL = default stream.  The call is
  *              asynchronous unless `stats` is non-NULL (then it synchronises
  *              the stream to read counters back).
+ * A scene handle supports ONE render in flight: its work buffers are shared by
+ * all calls.  A ray-queue overflow (RTAMD_ERR_QUEUE, the frame is incomplete) is
+ * returned by the call itself when `stats` is given, otherwise by the next render
+ * call on the scene or by rtamd_scene_destroy.
  */
 int rtamd_render(rtamd_scene *scene, const rtamd_render_params *params,
 		void *d_colour, void *d_hits, rtamd_render_stats *stats, void *stream);

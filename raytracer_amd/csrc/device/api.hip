@@ -33,6 +33,7 @@ int g_device = -1;
 
 const unsigned QUEUE_CAPACITY_MAX = 1u << 26;   // rays per bounce queue (80 B each)
 const unsigned QUEUE_CAPACITY_MIN = 1u << 16;
+const unsigned RT_SCAN_MAX_SEGMENTS = 4096;     // what k_scan_of_sums handles
 
 } // namespace
 
@@ -57,6 +58,11 @@ struct rtamd_scene {
 	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
 	unsigned bounce_capacity = 0;
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
+	int device = -1;             // the device the scene's buffers live on
+	unsigned queue_capacity_max = 0;
+	unsigned overflow_test_capacity = 0;
+	// queue-overflow count of the last asynchronous render, in host-visible memory
+	unsigned long long *h_overflow = nullptr, *d_overflow = nullptr;
 };
 
 namespace {
@@ -123,6 +129,8 @@ extern "C" const char *rtamd_version(void)
 	return "rtamd 0.1 (gfx950)";
 }
 
+static int take_sticky_overflow(rtamd_scene *sc);
+
 static void free_bounce_work(rtamd_scene *sc)
 {
 	BounceWork &w = sc->bounce;
@@ -147,8 +155,15 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 	if (sc->d_qcount) (void)hipFree(sc->d_qcount);
 	if (sc->d_counters) (void)hipFree(sc->d_counters);
 	free_bounce_work(sc);
+	int rc = 0;
+	if (sc->h_overflow) {
+		// the last asynchronous render may still be running
+		(void)hipDeviceSynchronize();
+		rc = take_sticky_overflow(sc);
+		(void)hipHostFree(sc->h_overflow);
+	}
 	delete sc;
-	return 0;
+	return rc;
 }
 
 static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
@@ -378,6 +393,24 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	sc->d_counters = static_cast<DevCounters *>(p);
 	HIP_TRY(hipMalloc(&p, sizeof(unsigned) * 128));
 	sc->d_qcount = static_cast<unsigned *>(p);
+	HIP_TRY(hipHostMalloc(&p, sizeof(unsigned long long), hipHostMallocMapped));
+	sc->h_overflow = static_cast<unsigned long long *>(p);
+	*sc->h_overflow = 0;
+	HIP_TRY(hipHostGetDevicePointer(&p, sc->h_overflow, 0));
+	sc->d_overflow = static_cast<unsigned long long *>(p);
+	sc->device = g_device;
+	{
+		// Test knobs.  RTAMD_QUEUE_CAPACITY bounds the size of the ray queues (frames are
+		// then rendered in more chunks).  RTAMD_QUEUE_OVERFLOW_AT makes the kernels treat
+		// the queues as that short although the chunks are sized for the real capacity:
+		// the only way to reach the overflow handling, which the chunk size otherwise
+		// rules out.
+		const char *cap = getenv("RTAMD_QUEUE_CAPACITY");
+		const unsigned long long c = cap ? strtoull(cap, nullptr, 0) : 0;
+		sc->queue_capacity_max = c >= RT_BLOCK && c < QUEUE_CAPACITY_MAX ? (unsigned)c : QUEUE_CAPACITY_MAX;
+		const char *at = getenv("RTAMD_QUEUE_OVERFLOW_AT");
+		sc->overflow_test_capacity = at ? (unsigned)strtoul(at, nullptr, 0) : 0;
+	}
 	return 0;
 }
 
@@ -484,41 +517,223 @@ static int ensure_glibc_table(rtamd_scene *sc, uint32_t seed, hipStream_t stream
 	return 0;
 }
 
-extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, void *d_colour, void *d_hits,
-		rtamd_render_stats *stats, void *stream_v)
+// Device buffers one render call works in.  rtamd_render takes them from the
+// scene (allocated on first use, grown when a larger frame comes);
+// rtamd_render_noalloc carves them out of this device's static scratch array.
+struct RenderWork {
+	long long *accum;            // 3 x int64 per owned pixel, or null (direct frames)
+	QueueItem *queue[2];
+	unsigned queue_capacity;
+	unsigned *qcount;            // 128 counters, one per bounce level
+	DevCounters *counters;
+	BounceWork bounce;           // hits == null: unsorted bounce pass
+	const int32_t *glibc;
+};
+
+// Owns the HIP events of one call so that every return path releases them.
+struct EventSet {
+	hipEvent_t whole[2] = { nullptr, nullptr };
+	std::vector<hipEvent_t> chunks;
+	~EventSet()
+	{
+		for (hipEvent_t e : chunks)
+			(void)hipEventDestroy(e);
+		for (hipEvent_t e : whole)
+			if (e)
+				(void)hipEventDestroy(e);
+	}
+};
+const size_t MAX_TIMED_CHUNKS = 2048;
+
+// worst-case children per primary sample at any level (shading.c:88: only depths 0
+// and 1 fan out)
+static unsigned long long queue_fan(const rtamd_scene *sc)
+{
+	const DevScene &dev = sc->dev;
+	if (!(dev.any_reflective && sc->glossy))
+		return 1;
+	const unsigned long long rs = (unsigned)(dev.reflection_samples > 1 ? dev.reflection_samples : 1);
+	return dev.max_reflections >= 2 ? rs * rs : rs;
+}
+
+// A queue overflow of an earlier asynchronous call: the resolve step of that call
+// left the count in host-visible memory.
+static int take_sticky_overflow(rtamd_scene *sc)
+{
+	if (sc->h_overflow && *sc->h_overflow) {
+		rtamd_set_error("a ray queue overflowed in an earlier render of this scene (%llu rays dropped): "
+				"that frame is incomplete", (unsigned long long)*sc->h_overflow);
+		*sc->h_overflow = 0;
+		return RTAMD_ERR_QUEUE;
+	}
+	return 0;
+}
+
+static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const RenderWork &w, bool direct,
+		unsigned long long pixels, void *d_colour, void *d_hits, rtamd_render_stats *stats, hipStream_t stream)
+{
+	const DevScene &dev = sc->dev;
+	const unsigned long long samples = pixels * (unsigned)dev.spp;
+	const unsigned long long fan = queue_fan(sc);
+	unsigned long long chunk = samples;
+	if (dev.any_reflective) {
+		chunk = w.queue_capacity / fan;
+		chunk -= chunk % RT_BLOCK;
+		if (chunk < RT_BLOCK) {
+			rtamd_set_error("reflection_samples %d needs a larger ray queue than %u entries",
+					dev.reflection_samples, w.queue_capacity);
+			return RTAMD_ERR_LIMIT;
+		}
+	}
+	// one launch covers at most 2^31 - 1 workgroups
+	const unsigned long long max_chunk = 0x7fffffffull * RT_BLOCK;
+	if (chunk > max_chunk)
+		chunk = max_chunk - max_chunk % RT_BLOCK;
+
+	unsigned kernel_capacity = w.queue_capacity;
+	if (sc->overflow_test_capacity && sc->overflow_test_capacity < kernel_capacity)
+		kernel_capacity = sc->overflow_test_capacity;
+
+	EventSet ev;
+	if (stats) {
+		HIP_TRY(hipEventCreate(&ev.whole[0]));
+		HIP_TRY(hipEventCreate(&ev.whole[1]));
+		HIP_TRY(hipEventRecord(ev.whole[0], stream));
+	}
+	if (!direct)
+		HIP_TRY(hipMemsetAsync(w.accum, 0, pixels * 3 * sizeof(long long), stream));
+	HIP_TRY(hipMemsetAsync(w.counters, 0, sizeof(DevCounters), stream));
+
+	int launches_primary = 0, launches_bounce = 0;
+	const int levels = dev.any_reflective ? dev.max_reflections : 0;
+	unsigned bounce_grid = 0;
+	if (levels) {
+		unsigned long long blocks = ((unsigned long long)w.queue_capacity + RT_BLOCK - 1) / RT_BLOCK;
+		bounce_grid = blocks > 2048 ? 2048u : (unsigned)blocks;
+	}
+	for (unsigned long long first = 0; first < samples; first += chunk) {
+		unsigned long long count = samples - first < chunk ? samples - first : chunk;
+		if (levels)
+			HIP_TRY(hipMemsetAsync(w.qcount, 0, sizeof(unsigned) * 128, stream));
+		const bool timed = stats && ev.chunks.size() < 2 * MAX_TIMED_CHUNKS;
+		if (timed) {
+			hipEvent_t e = nullptr;
+			HIP_TRY(hipEventCreate(&e));
+			ev.chunks.push_back(e);
+			HIP_TRY(hipEventRecord(e, stream));
+		}
+		HIP_TRY(rt_launch_primary(dev, p, first, count, w.glibc, w.accum,
+				direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits),
+				levels ? w.queue[0] : nullptr, levels ? w.qcount : nullptr, kernel_capacity, w.counters, stream));
+		if (timed) {
+			hipEvent_t e = nullptr;
+			HIP_TRY(hipEventCreate(&e));
+			ev.chunks.push_back(e);
+			HIP_TRY(hipEventRecord(e, stream));
+		}
+		launches_primary++;
+		for (int level = 1; level <= levels; level++) {
+			// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
+			if (w.bounce.hits)
+				HIP_TRY(rt_launch_bounce_sorted(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
+						kernel_capacity, w.accum, level < levels ? w.queue[level & 1] : nullptr,
+						w.qcount + level, w.counters, w.bounce, bounce_grid, stream));
+			else
+				HIP_TRY(rt_launch_bounce(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
+						kernel_capacity, w.accum, level < levels ? w.queue[level & 1] : nullptr,
+						w.qcount + level, w.counters, bounce_grid, stream));
+			launches_bounce++;
+		}
+	}
+	HIP_TRY(rt_launch_collect_stats(w.counters, stream));
+	if (!direct)
+		HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, w.accum, static_cast<float *>(d_colour), w.counters,
+				sc->d_overflow, stream));
+
+	if (stats) {
+		std::memset(stats, 0, sizeof *stats);
+		HIP_TRY(hipEventRecord(ev.whole[1], stream));
+		HIP_TRY(hipEventSynchronize(ev.whole[1]));
+		HIP_TRY(hipEventElapsedTime(&stats->ms_total, ev.whole[0], ev.whole[1]));
+		float sum = 0.0f;
+		for (size_t i = 0; i + 1 < ev.chunks.size(); i += 2) {
+			float ms = 0.0f;
+			HIP_TRY(hipEventElapsedTime(&ms, ev.chunks[i], ev.chunks[i + 1]));
+			sum += ms;
+		}
+		// frames with more chunks than are timed: scaled from the timed ones
+		if ((size_t)launches_primary * 2 > ev.chunks.size() && !ev.chunks.empty())
+			sum *= (float)launches_primary / (float)(ev.chunks.size() / 2);
+		stats->ms_primary = sum;
+		DevCounters c;
+		HIP_TRY(hipMemcpy(&c, w.counters, sizeof c, hipMemcpyDeviceToHost));
+		stats->rays_primary = c.rays_primary;
+		stats->rays_shadow = c.rays_shadow;
+		stats->rays_secondary = c.rays_secondary;
+		stats->env_lookups = c.env_lookups;
+		stats->queue_peak = c.queue_peak;
+		stats->bvh_nodes = c.bvh_nodes;
+		stats->tri_tests = c.tri_tests;
+		stats->samples = samples;
+		stats->launches_primary = launches_primary;
+		stats->launches_bounce = launches_bounce;
+		if (c.queue_overflow) {
+			if (sc->h_overflow)
+				*sc->h_overflow = 0;      // reported here, not again by the next call
+			rtamd_set_error("a ray queue overflowed (%llu rays dropped)", c.queue_overflow);
+			return RTAMD_ERR_QUEUE;
+		}
+	}
+	return 0;
+}
+
+// Argument checks shared by the two render entry points.
+static int render_prepare(rtamd_scene *sc, const rtamd_render_params *params, void *d_colour, void *d_hits,
+		rtamd_render_params *p, unsigned long long *pixels, bool *direct)
 {
 	if (!sc || !d_colour) {
 		rtamd_set_error("rtamd_render: NULL scene or output");
 		return RTAMD_ERR_ARG;
 	}
-	hipStream_t stream = static_cast<hipStream_t>(stream_v);
-	rtamd_render_params p;
-	int rc = normalise_params(sc->dev.width, sc->dev.height, params, &p);
+	int rc = take_sticky_overflow(sc);
 	if (rc)
 		return rc;
-	if (p.rng_mode == RTAMD_RNG_GLIBC) {
-		if (!sc->fixed_consumption) {
-			rtamd_set_error("RTAMD_RNG_GLIBC needs a scene whose rand() consumption is fixed (no area "
-					"light, no glossy material); use RTAMD_RNG_KEYED");
-			return RTAMD_ERR_ARG;
-		}
-		if ((rc = ensure_glibc_table(sc, p.seed, stream)))
-			return rc;
+	if ((rc = normalise_params(sc->dev.width, sc->dev.height, params, p)))
+		return rc;
+	if (p->rng_mode == RTAMD_RNG_GLIBC && !sc->fixed_consumption) {
+		rtamd_set_error("RTAMD_RNG_GLIBC needs a scene whose rand() consumption is fixed (no area "
+				"light, no glossy material); use RTAMD_RNG_KEYED");
+		return RTAMD_ERR_ARG;
 	}
-	if (d_hits && p.tile_stride != 1) {
+	if (d_hits && p->tile_stride != 1) {
 		rtamd_set_error("hit records are only available for single-owner renders (tile_stride 1)");
 		return RTAMD_ERR_ARG;
 	}
-	const DevScene &dev = sc->dev;
-	const unsigned long long pixels = rt_owned_pixels(dev.width, dev.height, p);
-	const unsigned long long samples = pixels * (unsigned)dev.spp;
-	if (pixels > 0xffffffffull) {
+	*pixels = rt_owned_pixels(sc->dev.width, sc->dev.height, *p);
+	if (*pixels > 0xffffffffull) {
 		rtamd_set_error("too many pixels per call");
 		return RTAMD_ERR_LIMIT;
 	}
 	// Without reflections, and with all samples of a pixel inside one wave, the
 	// primary kernel writes finished pixels itself: no accumulators, no resolve.
-	const bool direct = !dev.any_reflective && 64 % dev.spp == 0;
+	*direct = !sc->dev.any_reflective && 64 % sc->dev.spp == 0;
+	return 0;
+}
+
+extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, void *d_colour, void *d_hits,
+		rtamd_render_stats *stats, void *stream_v)
+{
+	hipStream_t stream = static_cast<hipStream_t>(stream_v);
+	rtamd_render_params p;
+	unsigned long long pixels = 0;
+	bool direct = false;
+	int rc = render_prepare(sc, params, d_colour, d_hits, &p, &pixels, &direct);
+	if (rc)
+		return rc;
+	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
+		return rc;
+	const DevScene &dev = sc->dev;
+	const unsigned long long samples = pixels * (unsigned)dev.spp;
 	// work buffers
 	if (!direct && sc->accum_slots < pixels) {
 		if (sc->d_accum) {
@@ -532,17 +747,9 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		sc->d_accum = static_cast<long long *>(ptr);
 		sc->accum_slots = pixels;
 	}
-	// worst-case children per primary sample at any level (shading.c:88: only
-	// depths 0 and 1 fan out)
-	unsigned long long fan = 1;
-	if (dev.any_reflective && sc->glossy) {
-		unsigned long long rs = (unsigned)(dev.reflection_samples > 1 ? dev.reflection_samples : 1);
-		fan = dev.max_reflections >= 2 ? rs * rs : rs;
-	}
-	unsigned long long chunk = samples;
 	if (dev.any_reflective) {
-		unsigned long long want = samples * fan;
-		unsigned cap = want > QUEUE_CAPACITY_MAX ? QUEUE_CAPACITY_MAX
+		unsigned long long want = samples * queue_fan(sc);
+		unsigned cap = want > sc->queue_capacity_max ? sc->queue_capacity_max
 				: (want < QUEUE_CAPACITY_MIN ? QUEUE_CAPACITY_MIN : (unsigned)want);
 		if (sc->queue_capacity < cap) {
 			HIP_TRY(hipStreamSynchronize(stream));
@@ -569,107 +776,23 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			HIP_TRY(hipMalloc(&ptr, n * sizeof(BounceBin)));   sc->bounce.bins = static_cast<BounceBin *>(ptr);
 			HIP_TRY(hipMalloc(&ptr, n * sizeof(unsigned)));    sc->bounce.perm = static_cast<unsigned *>(ptr);
 			HIP_TRY(hipMalloc(&ptr, n_bins * sizeof(unsigned)));  sc->bounce.hist = static_cast<unsigned *>(ptr);
-			HIP_TRY(hipMalloc(&ptr, 4096 * sizeof(unsigned))); sc->bounce.sums = static_cast<unsigned *>(ptr);
+			HIP_TRY(hipMalloc(&ptr, RT_SCAN_MAX_SEGMENTS * sizeof(unsigned))); sc->bounce.sums = static_cast<unsigned *>(ptr);
 			HIP_TRY(hipMalloc(&ptr, 8 * sizeof(unsigned)));    sc->bounce.bounds = static_cast<unsigned *>(ptr);
 			sc->bounce_capacity = sc->queue_capacity;
 		}
-		chunk = sc->queue_capacity / fan;
-		chunk -= chunk % RT_BLOCK;
-		if (chunk < RT_BLOCK) {
-			rtamd_set_error("reflection_samples %d needs a larger ray queue than %u entries",
-					dev.reflection_samples, sc->queue_capacity);
-			return RTAMD_ERR_LIMIT;
-		}
 	}
-
-	hipEvent_t ev[2] = { nullptr, nullptr };
-	std::vector<hipEvent_t> pev;
-	if (stats) {
-		HIP_TRY(hipEventCreate(&ev[0]));
-		HIP_TRY(hipEventCreate(&ev[1]));
-		HIP_TRY(hipEventRecord(ev[0], stream));
-	}
-	if (!direct)
-		HIP_TRY(hipMemsetAsync(sc->d_accum, 0, pixels * 3 * sizeof(long long), stream));
-	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, sizeof(DevCounters), stream));
-
-	int launches_primary = 0, launches_bounce = 0;
-	const int levels = dev.any_reflective ? dev.max_reflections : 0;
-	unsigned bounce_grid = 0;
-	if (levels) {
-		unsigned long long blocks = ((unsigned long long)sc->queue_capacity + RT_BLOCK - 1) / RT_BLOCK;
-		bounce_grid = blocks > 2048 ? 2048u : (unsigned)blocks;
-	}
-	for (unsigned long long first = 0; first < samples; first += chunk) {
-		unsigned long long count = samples - first < chunk ? samples - first : chunk;
-		if (levels)
-			HIP_TRY(hipMemsetAsync(sc->d_qcount, 0, sizeof(unsigned) * 128, stream));
-		if (stats && pev.size() < 4096) {
-			hipEvent_t a, b;
-			HIP_TRY(hipEventCreate(&a));
-			HIP_TRY(hipEventCreate(&b));
-			pev.push_back(a);
-			pev.push_back(b);
-			HIP_TRY(hipEventRecord(a, stream));
-		}
-		HIP_TRY(rt_launch_primary(dev, p, first, count, sc->d_glibc, sc->d_accum,
-				direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits), levels ? sc->d_queue[0] : nullptr,
-				levels ? sc->d_qcount : nullptr, sc->queue_capacity, sc->d_counters, stream));
-		if (stats && pev.size() <= 4096 && !pev.empty())
-			HIP_TRY(hipEventRecord(pev.back(), stream));
-		launches_primary++;
-		for (int level = 1; level <= levels; level++) {
-			// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
-			if (sc->sorted_bounce)
-				HIP_TRY(rt_launch_bounce_sorted(dev, sc->d_queue[(level - 1) & 1], sc->d_qcount + (level - 1),
-						sc->queue_capacity, sc->d_accum, level < levels ? sc->d_queue[level & 1] : nullptr,
-						sc->d_qcount + level, sc->d_counters, sc->bounce, bounce_grid, stream));
-			else
-				HIP_TRY(rt_launch_bounce(dev, sc->d_queue[(level - 1) & 1], sc->d_qcount + (level - 1),
-						sc->queue_capacity, sc->d_accum, level < levels ? sc->d_queue[level & 1] : nullptr,
-						sc->d_qcount + level, sc->d_counters, bounce_grid, stream));
-			launches_bounce++;
-		}
-	}
-	HIP_TRY(rt_launch_collect_stats(sc->d_counters, stream));
-	if (!direct)
-		HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, sc->d_accum, static_cast<float *>(d_colour), sc->d_counters,
-				stream));
-
-	if (stats) {
-		std::memset(stats, 0, sizeof *stats);
-		HIP_TRY(hipEventRecord(ev[1], stream));
-		HIP_TRY(hipEventSynchronize(ev[1]));
-		HIP_TRY(hipEventElapsedTime(&stats->ms_total, ev[0], ev[1]));
-		float sum = 0.0f;
-		for (size_t i = 0; i + 1 < pev.size(); i += 2) {
-			float ms = 0.0f;
-			HIP_TRY(hipEventElapsedTime(&ms, pev[i], pev[i + 1]));
-			sum += ms;
-		}
-		stats->ms_primary = sum;
-		for (hipEvent_t e : pev)
-			(void)hipEventDestroy(e);
-		(void)hipEventDestroy(ev[0]);
-		(void)hipEventDestroy(ev[1]);
-		DevCounters c;
-		HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
-		stats->rays_primary = c.rays_primary;
-		stats->rays_shadow = c.rays_shadow;
-		stats->rays_secondary = c.rays_secondary;
-		stats->env_lookups = c.env_lookups;
-		stats->queue_peak = c.queue_peak;
-		stats->bvh_nodes = c.bvh_nodes;
-		stats->tri_tests = c.tri_tests;
-		stats->samples = samples;
-		stats->launches_primary = launches_primary;
-		stats->launches_bounce = launches_bounce;
-		if (c.queue_overflow) {
-			rtamd_set_error("a ray queue overflowed (%llu rays dropped)", c.queue_overflow);
-			return RTAMD_ERR_QUEUE;
-		}
-	}
-	return 0;
+	RenderWork w;
+	w.accum = direct ? nullptr : sc->d_accum;
+	w.queue[0] = sc->d_queue[0];
+	w.queue[1] = sc->d_queue[1];
+	w.queue_capacity = sc->queue_capacity;
+	w.qcount = sc->d_qcount;
+	w.counters = sc->d_counters;
+	w.bounce = sc->bounce;
+	if (!sc->sorted_bounce)
+		w.bounce.hits = nullptr;
+	w.glibc = sc->d_glibc;
+	return render_impl(sc, p, w, direct, pixels, d_colour, d_hits, stats, stream);
 }
 
 extern "C" int rtamd_trace(rtamd_scene *sc, const void *d_rays, uint64_t n, void *d_hits, void *stream_v)
@@ -700,6 +823,10 @@ extern "C" int rtamd_camera_rays(rtamd_scene *sc, const rtamd_render_params *par
 		return rc;
 	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
 		return rc;
+	if (rt_owned_pixels(sc->dev.width, sc->dev.height, p) * (unsigned)sc->dev.spp > 0x7fffffffull * 256) {
+		rtamd_set_error("rtamd_camera_rays: too many samples in one call");
+		return RTAMD_ERR_LIMIT;
+	}
 	HIP_TRY(rt_launch_camera_rays(sc->dev, p, sc->d_glibc, static_cast<double *>(d_rays), stream));
 	return 0;
 }

@@ -32,7 +32,7 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueItem *queue_in
 		DevCounters *counters, const BounceWork &work, unsigned grid_blocks, hipStream_t stream);
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
 		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
-		hipStream_t stream);
+		unsigned long long *overflow_out, hipStream_t stream);
 hipError_t rt_launch_collect_stats(DevCounters *counters, hipStream_t stream);
 hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
 		rtamd_hit_record *hits, hipStream_t stream);

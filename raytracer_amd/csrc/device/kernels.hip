@@ -660,9 +660,13 @@ __global__ void k_collect_stats(DevCounters *counters)
 // Accumulators -> the reference's float RGBA frame (raytracer.c:46,81): the
 // per-pixel sum is scaled by the float 1.0/aa^2 when antialiasing is on.
 __global__ void k_resolve(DevScene sc, TileMap tm, unsigned long long pixel_first, unsigned long long pixel_count,
-		const long long *accum, float *colour)
+		const long long *accum, float *colour, const DevCounters *counters, unsigned long long *overflow_out)
 {
 	unsigned long long local = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	// the last kernel of a reflective frame leaves a queue overflow where the host
+	// finds it without waiting for the stream (host-visible memory)
+	if (local == 0 && overflow_out && counters->queue_overflow)
+		*overflow_out = counters->queue_overflow;
 	if (local >= pixel_count)
 		return;
 	unsigned long long pix = pixel_first + local;
@@ -844,14 +848,14 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueItem *queue_in
 
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
 		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
-		hipStream_t stream)
+		unsigned long long *overflow_out, hipStream_t stream)
 {
 	if (!pixel_count)
 		return hipSuccess;
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long blocks = (pixel_count + 255) / 256;
 	hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, stream, sc, tm, pixel_first, pixel_count,
-			accum, colour);
+			accum, colour, counters, overflow_out);
 	return hipGetLastError();
 }
 

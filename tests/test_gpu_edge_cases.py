@@ -128,3 +128,28 @@ def test_limits_are_reported_not_clamped(render, tmp_path):
     for cfg in (dict(aa_samples=65), dict(shadow_samples=65), dict(reflection_samples=257), dict(max_reflections=61)):
         with pytest.raises(RuntimeError):
             render.DeviceScene(blob.with_config(**cfg)).close()
+
+
+def test_queue_overflow_is_reported_and_harmless(render, tmp_path, monkeypatch):
+    """A ray queue too small for the frame: the call with stats reports it, the
+    asynchronous call reports it through the next call on the scene, nothing is
+    written out of bounds (the frame is merely incomplete), and the scene renders
+    correctly again once the queue is large enough."""
+    import torch
+    body = FLOOR.replace("grey", "shiny") + (
+        '<Translate vector="0 1.2 0"><Shape geometry="torus" material="shiny" /></Translate>\n')
+    blob = write_scene(tmp_path, "overflow", body, w=64, h=48, aa=2, ss=2)
+    monkeypatch.setenv("RTAMD_QUEUE_OVERFLOW_AT", "300")
+    dev = render.DeviceScene(blob)
+    monkeypatch.delenv("RTAMD_QUEUE_OVERFLOW_AT")
+    p = render.make_params(rng_mode=_abi.RNG_KEYED)
+    with pytest.raises(_abi.RtamdError) as e:
+        dev.render(p)
+    assert e.value.status == -7
+    frame, _, _ = dev.render(p, want_stats=False)     # asynchronous: returns 0
+    torch.cuda.synchronize()
+    with pytest.raises(_abi.RtamdError) as e:
+        dev.render(p, want_stats=False)
+    assert e.value.status == -7 and "earlier render" in str(e.value)
+    dev.close()
+    check(render, blob)
