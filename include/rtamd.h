@@ -247,6 +247,22 @@ typedef struct rtamd_render_stats {
 int rtamd_render(rtamd_scene *scene, const rtamd_render_params *params,
 		void *d_colour, void *d_hits, rtamd_render_stats *stats, void *stream);
 
+/* rtamd_render for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same frame, bit for bit, as rtamd_render
+ * with d_hits = NULL and stats = NULL; asynchronous on `stream`.  All work
+ * memory (accumulators, ray queues, sort scratch, counters) comes from one
+ * static array of 128 MiB that every GPU the library runs on holds until the
+ * process ends; the call makes no hipMalloc / hipFree.  Limits, reported as
+ * RTAMD_ERR_LIMIT / RTAMD_ERR_ARG: the accumulators of a reflective frame (24
+ * bytes per owned pixel) and at least one workgroup's worth of queued rays must
+ * fit into the array; RTAMD_RNG_GLIBC is accepted only without antialiasing.
+ * Calls on one GPU share the array: calls that overlap in time (other streams,
+ * other scenes) race; serialise them.  A queue overflow is reported by the next
+ * render call on the scene or by rtamd_scene_destroy. */
+int rtamd_render_noalloc(rtamd_scene *scene, const rtamd_render_params *params,
+		void *d_colour, void *stream);
+
 /* Replaces `bool ray_intersect(Ray, Hit*)` (ray.h:25, ray.c:643-672) for a
  * batch.  d_rays: DEVICE double[8*n] = origin xyz, direction xyz, near, far
  * (near/far are narrowed to float like Ray.near/far, ray.h:10-11).

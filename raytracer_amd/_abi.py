@@ -114,6 +114,7 @@ PROTOTYPES = {
     "rtamd_scene_destroy": (C.c_int, [C.c_void_p]),
     "rtamd_render": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                C.POINTER(RenderStats), C.c_void_p]),
+    "rtamd_render_noalloc": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
     "rtamd_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rtamd_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p,
                                     C.c_void_p]),

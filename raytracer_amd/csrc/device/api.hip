@@ -100,6 +100,8 @@ bool float_valued(double v)
 
 } // namespace
 
+static int scratch_init(int device);
+
 extern "C" int rtamd_init(int device)
 {
 	int count = 0;
@@ -114,6 +116,9 @@ extern "C" int rtamd_init(int device)
 		return RTAMD_ERR_ARG;
 	}
 	HIP_TRY(hipSetDevice(device));
+	int rc = scratch_init(device);
+	if (rc)
+		return rc;
 	g_device = device;
 	return 0;
 }
@@ -793,6 +798,119 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		w.bounce.hits = nullptr;
 	w.glibc = sc->d_glibc;
 	return render_impl(sc, p, w, direct, pixels, d_colour, d_hits, stats, stream);
+}
+
+// ---- the entry point that allocates nothing ------------------------------------
+//
+// One array per GPU, present from the moment the library's code object is loaded
+// until the process ends.  Host code never uses the array's name as an address:
+// rtamd_init asks HIP for the array's device address on the device it selects and
+// keeps it in g_scratch_ptr.
+#define RTAMD_NOALLOC_SCRATCH_BYTES (128ull << 20)
+static __device__ __align__(256) unsigned char scratch[RTAMD_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+const int MAX_DEVICES = 64;
+unsigned char *g_scratch_ptr[MAX_DEVICES];
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}
+
+// Called by rtamd_init with `device` current.
+static int scratch_init(int device)
+{
+	if (device < 0 || device >= MAX_DEVICES) {
+		rtamd_set_error("device %d is beyond the %d devices this library keeps scratch addresses for", device,
+				MAX_DEVICES);
+		return RTAMD_ERR_LIMIT;
+	}
+	if (g_scratch_ptr[device])
+		return 0;
+	void *ptr = nullptr;
+	HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+	g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+	return 0;
+}
+
+extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *params, void *d_colour,
+		void *stream_v)
+{
+	hipStream_t stream = static_cast<hipStream_t>(stream_v);
+	rtamd_render_params p;
+	unsigned long long pixels = 0;
+	bool direct = false;
+	int rc = render_prepare(sc, params, d_colour, nullptr, &p, &pixels, &direct);
+	if (rc)
+		return rc;
+	if (p.rng_mode == RTAMD_RNG_GLIBC && sc->dev.antialiasing) {
+		rtamd_set_error("rtamd_render_noalloc: RTAMD_RNG_GLIBC with antialiasing needs a table of the rand() "
+				"stream, which this entry point does not allocate; use RTAMD_RNG_KEYED or rtamd_render");
+		return RTAMD_ERR_ARG;
+	}
+	unsigned char *base = (sc->device >= 0 && sc->device < MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;
+	if (!base) {
+		rtamd_set_error("rtamd_render_noalloc: no scratch address for device %d (rtamd_init not called?)",
+				sc->device);
+		return RTAMD_ERR_ARG;
+	}
+	// Layout: counters | queue counters | hit-point bounds | scan sums | histogram |
+	// accumulators | queue 0 | queue 1 | hits | bins | order.
+	const bool sorted = sc->sorted_bounce && sc->dev.any_reflective;
+	const int bits = sc->bounce.bits < 6 ? sc->bounce.bits : 6;
+	const size_t n_bins = ((size_t)1 << (3 * bits)) + 1;
+	size_t off = 0;
+	RenderWork w;
+	std::memset(&w, 0, sizeof w);
+	w.counters = reinterpret_cast<DevCounters *>(base + off);  off = align_up(off + sizeof(DevCounters), 256);
+	w.qcount = reinterpret_cast<unsigned *>(base + off);       off = align_up(off + 128 * sizeof(unsigned), 256);
+	w.bounce.bounds = reinterpret_cast<unsigned *>(base + off); off = align_up(off + 8 * sizeof(unsigned), 256);
+	w.bounce.sums = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + RT_SCAN_MAX_SEGMENTS * sizeof(unsigned), 256);
+	w.bounce.bits = bits;
+	if (sorted) {
+		w.bounce.hist = reinterpret_cast<unsigned *>(base + off);
+		off = align_up(off + n_bins * sizeof(unsigned), 256);
+	}
+	if (!direct) {
+		const size_t bytes = (size_t)pixels * 3 * sizeof(long long);
+		if (bytes > RTAMD_NOALLOC_SCRATCH_BYTES - off) {
+			rtamd_set_error("rtamd_render_noalloc: %llu pixels of a reflective scene need %zu bytes of "
+					"accumulators; the scratch array holds %llu bytes (render fewer tiles per call, or use "
+					"rtamd_render)", pixels, bytes, RTAMD_NOALLOC_SCRATCH_BYTES);
+			return RTAMD_ERR_LIMIT;
+		}
+		w.accum = reinterpret_cast<long long *>(base + off);
+		off = align_up(off + bytes, 256);
+	}
+	if (sc->dev.any_reflective) {
+		const size_t per_entry = 2 * sizeof(QueueItem) + (sorted ? sizeof(BounceHit) + sizeof(BounceBin) + sizeof(unsigned) : 0);
+		size_t cap = (RTAMD_NOALLOC_SCRATCH_BYTES - off - 5 * 256) / per_entry;
+		cap -= cap % 256;
+		const unsigned long long want = pixels * (unsigned)sc->dev.spp * queue_fan(sc);
+		if (cap > want)
+			cap = (size_t)align_up((size_t)want, 256);
+		if (cap > sc->queue_capacity_max)
+			cap = sc->queue_capacity_max;
+		if (cap < queue_fan(sc) * RT_BLOCK) {
+			rtamd_set_error("rtamd_render_noalloc: the scratch array leaves room for %zu queued rays, fewer "
+					"than one workgroup of samples can spawn (%llu); use rtamd_render", cap,
+					queue_fan(sc) * RT_BLOCK);
+			return RTAMD_ERR_LIMIT;
+		}
+		w.queue_capacity = (unsigned)cap;
+		w.queue[0] = reinterpret_cast<QueueItem *>(base + off);  off = align_up(off + cap * sizeof(QueueItem), 256);
+		w.queue[1] = reinterpret_cast<QueueItem *>(base + off);  off = align_up(off + cap * sizeof(QueueItem), 256);
+		if (sorted) {
+			w.bounce.hits = reinterpret_cast<BounceHit *>(base + off);  off = align_up(off + cap * sizeof(BounceHit), 256);
+			w.bounce.bins = reinterpret_cast<BounceBin *>(base + off);  off = align_up(off + cap * sizeof(BounceBin), 256);
+			w.bounce.perm = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + cap * sizeof(unsigned), 256);
+		}
+	}
+	if (off > RTAMD_NOALLOC_SCRATCH_BYTES) {
+		rtamd_set_error("rtamd_render_noalloc: internal layout error (%zu bytes)", off);
+		return RTAMD_ERR_LIMIT;
+	}
+	w.glibc = nullptr;
+	return render_impl(sc, p, w, direct, pixels, d_colour, nullptr, nullptr, stream);
 }
 
 extern "C" int rtamd_trace(rtamd_scene *sc, const void *d_rays, uint64_t n, void *d_hits, void *stream_v)

@@ -1,0 +1,69 @@
+"""rtamd_render_noalloc (the entry point that takes all its work memory from the
+library's static per-GPU scratch array) against rtamd_render, through the C ABI:
+the frames must be bit-identical, on two calls in a row, the second on a
+smaller input - the array keeps the first call's contents, so whatever must
+start at zero has to be cleared by the call itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import raytracer_amd as ra
+from raytracer_amd import _abi
+from conftest import scene_path
+
+
+def frames(render, blob, params):
+    import torch
+    dev = render.DeviceScene(blob)
+    want, _, _ = dev.render(params)
+    got = torch.full((blob.height, blob.width, 4), -7.0, dtype=torch.float32, device=dev.device)
+    s = torch.cuda.current_stream(dev.device)
+    _abi.check(_abi.lib().rtamd_render_noalloc(dev._handle, C.byref(params), got.data_ptr(), s.cuda_stream),
+               "rtamd_render_noalloc")
+    torch.cuda.synchronize()
+    out = got.cpu().numpy(), want.cpu().numpy()
+    dev.close()
+    return out
+
+
+def test_noalloc_matches_render_twice_second_smaller():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from raytracer_amd import render
+    render.init(0)
+    p = render.make_params(rng_mode=_abi.RNG_KEYED)
+    # glossy + mirror + area lights: accumulators, both queues and the sort scratch are used
+    big = ra.load_sdl(scene_path("8-glossy")).with_config(width=40, height=32, antialiasing=1, aa_samples=4)
+    got, want = frames(render, big, p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert want[..., :3].max() > 0.1
+    small = ra.load_sdl(scene_path("7-reflections")).with_config(width=17, height=9, antialiasing=1, aa_samples=3)
+    got, want = frames(render, small, p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a scene without reflections writes pixels directly (no scratch besides the counters)
+    direct = ra.load_sdl(scene_path("6-soft")).with_config(width=24, height=12, antialiasing=1, aa_samples=2)
+    got, want = frames(render, direct, p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_noalloc_rejects_what_does_not_fit():
+    import torch
+    from raytracer_amd import render
+    render.init(0)
+    blob = ra.load_sdl(scene_path("8-glossy")).with_config(width=4096, height=2048)
+    dev = render.DeviceScene(blob)
+    frame = dev.new_frame()
+    p = render.make_params(rng_mode=_abi.RNG_KEYED)
+    rc = _abi.lib().rtamd_render_noalloc(dev._handle, C.byref(p), frame.data_ptr(), None)
+    assert rc == -6 and b"scratch" in _abi.lib().rtamd_last_error()
+    blob = ra.load_sdl(scene_path("3-aa")).with_config(width=16, height=16)
+    dev2 = render.DeviceScene(blob)
+    p = render.make_params(rng_mode=_abi.RNG_GLIBC)
+    rc = _abi.lib().rtamd_render_noalloc(dev2._handle, C.byref(p), frame.data_ptr(), None)
+    assert rc == -1 and b"RTAMD_RNG_GLIBC" in _abi.lib().rtamd_last_error()
+    dev.close()
+    dev2.close()
