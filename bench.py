@@ -52,19 +52,12 @@ def algorithmic_flops(st):
 
 
 def measured_traffic(scene):
-    """HBM bytes per k_primary launch on this workload, from the committed counter
-    passes (FETCH_SIZE doubled as the gfx950 correction requires, plus
-    WRITE_SIZE; both in KB).  Counters cannot be read from inside this process,
-    so the figure comes from profiles/ and is null when no profile matches."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("workload") == scene:
-            return t["bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """HBM bytes per k_primary launch on this workload (2 x FETCH_SIZE + WRITE_SIZE
+    in KB, the gfx950 correction), from the committed counter passes; counters
+    cannot be read from inside this process, so the figure is null when no profile
+    of this workload is present."""
+    t = measured_counters(scene)
+    return t["bytes_per_launch"] if t else None
 
 
 def cpu_baseline(blob):
@@ -102,39 +95,109 @@ def cpu_baseline(blob):
     return out, port
 
 
+def measured_counters(scene):
+    """Hardware counters of k_primary on this workload, from the committed counter
+    passes (profiles/bench_pmc.json, written by scripts/collect_profiles.sh on the
+    GPU box for the same scene at the same size).  None when no profile matches."""
+    path = os.path.join(ROOT, "profiles", "bench_pmc.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("workload") == scene:
+            return t
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one fresh process per
+    rank (this parent has made no GPU call and makes none), wait for them, pass
+    rank 0's JSON line through.  Ranks that die take the others down with them."""
+    port = free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + 3000
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            r = p.poll()
+            if r is not None:
+                pending.remove(p)
+                if r != 0:
+                    rc = rc or r
+        if rc or time.time() > deadline:
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 1
+            break
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default=WORKLOAD)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo rehearses the N-rank path on fewer GPUs than ranks (ranks share devices)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     blob = ra.load_sdl(os.path.join(ROOT, "assets", args.scene + ".sdl"))
     scene = render.DeviceScene(blob, device=local_rank)
     base = render.make_params(rng_mode=_abi.RNG_KEYED, tile=(32, 32))
     frame = scene.new_frame()
+    gather = rdist.FrameGather(frame, base, rank, world)
+    # reductions of scalars: on the device over RCCL, on the host over gloo
+    red_dev = scene.device if args.backend == "nccl" else "cpu"
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step(want_stats=False):
-        return rdist.render_frame(scene, base, rank, world, frame=frame, want_stats=want_stats)
+        return rdist.render_frame(scene, base, rank, world, frame=frame, want_stats=want_stats, gather=gather)
 
     for _ in range(args.warmup):
         step()
@@ -143,7 +206,7 @@ def main():
     _, st = step(want_stats=True)
     rays_local = render.total_rays(st)
     counts = torch.tensor([rays_local, st.rays_primary, st.rays_shadow, st.rays_secondary],
-                          dtype=torch.float64, device=scene.device)
+                          dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
     rays_frame = int(counts[0].item())
@@ -159,7 +222,7 @@ def main():
         kernel_launches += sti.launches_primary
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=scene.device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -175,25 +238,44 @@ def main():
             "config": {"workload": f"{args.scene}.sdl {blob.width}x{blob.height} {blob.spp} spp, "
                                    "keyed samples, 32x32 tiles dealt cyclically over ranks, "
                                    "framebuffer gather to rank 0",
-                       "rays_per_frame": rays_frame, "ms_per_frame": ms_per_step},
+                       "rays_per_frame": rays_frame, "ms_per_frame": ms_per_step,
+                       "backend": args.backend if world > 1 else None},
         }
         cpu, port = (None, None)
         if world == 1 and not args.no_cpu:
             cpu, port = cpu_baseline(blob)
-        if port:
-            # dominant kernel: k_primary (camera ray, nearest hit, shadow rays, shading)
-            flops_per_ray = algorithmic_flops(port) / port["rays"]
-            kernel_ms = kernel_ms_sum / max(1, kernel_launches)
-            launches_per_frame = max(1, st.launches_primary)
-            achieved = flops_per_ray * (rays_local / launches_per_frame) / (kernel_ms * 1e-3) / 1e12
-            result["roofline"] = {
-                "bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VECTOR_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VECTOR_TFLOPS,
+        kernel_ms = kernel_ms_sum / max(1, kernel_launches)
+        launches_per_frame = max(1, st.launches_primary)
+        rays_per_launch = rays_local / launches_per_frame
+        pmc = measured_counters(args.scene) if world == 1 else None
+        roof = {"bound": "valu", "kernel": "k_primary", "kernel_ms": kernel_ms, "unit": "TFLOP/s",
+                "peak": PEAK_FP64_VECTOR_TFLOPS, "achieved": None, "frac": None,
                 "traffic": measured_traffic(args.scene),
-                "kernel": "k_primary", "kernel_ms": kernel_ms,
-                "flops_per_ray": flops_per_ray,
-                "note": "vector-ALU bound (no dense contraction, scene data cache resident); "
-                        "peak = FP64 vector rate, the arithmetic that decides hits is double"}
+                "note": "vector-ALU bound: no dense contraction, scene data cache resident, HBM traffic "
+                        "negligible.  achieved = floating-point operations the kernel EXECUTED per launch "
+                        "(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/F64 x active lanes, FMA = 2; counter passes "
+                        "of this workload in profiles/bench_pmc.json) / the kernel time measured here; "
+                        "peak = 78.65 TFLOP/s, the vector FMA rate both FP64 and unpacked FP32 issue at.  "
+                        "Most issued instructions are not flops (min/max, compares, conversions, integer "
+                        "and mask work): valu_busy is the issue-slot occupancy that bounds the kernel."}
+        if pmc and kernel_ms > 0:
+            flops = pmc["flops_executed_per_launch"] * (rays_per_launch / pmc["rays_per_launch"])
+            achieved = flops / (kernel_ms * 1e-3) / 1e12
+            roof.update({
+                "achieved": achieved, "frac": achieved / PEAK_FP64_VECTOR_TFLOPS,
+                "frac_vs_fp32_peak": achieved / (2 * PEAK_FP64_VECTOR_TFLOPS),
+                "valu_busy": pmc["valu_busy"], "valu_insts_per_ray": pmc["valu_insts_per_ray"],
+                "fp64_inst_share": pmc["fp64_inst_share"], "lane_utilisation": pmc["lane_utilisation"],
+                "salu_per_valu": pmc["salu_per_valu"], "counters_kernel_ms": pmc["kernel_ms"]})
+        if port:
+            # the survey's implementation-independent model of the REFERENCE's work for these
+            # rays (not executed flops): kept for comparison with the survey's roof
+            flops_per_ray = algorithmic_flops(port) / port["rays"]
+            nominal = flops_per_ray * rays_per_launch / (kernel_ms * 1e-3) / 1e12
+            roof.update({"nominal_reference_flops_per_ray": flops_per_ray,
+                         "nominal_reference_tflops": nominal,
+                         "nominal_frac_of_fp64_peak": nominal / PEAK_FP64_VECTOR_TFLOPS})
+        result["roofline"] = roof
         if cpu:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = value / cpu["value"]

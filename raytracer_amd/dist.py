@@ -16,21 +16,60 @@ import torch.distributed as dist
 from . import _abi, tiles
 
 
-def _pack(frame, params):
-    """Owner's tiles of `frame` -> dense [max_owned, th, tw, 4] tensor."""
-    h, w, _ = frame.shape
-    tw, th = params.tile_w, params.tile_h
-    nmax = tiles.max_owned_count(w, h, tw, th, params.tile_stride)
-    if frame.is_cuda:
-        packed = torch.zeros((nmax, th, tw, 4), dtype=torch.float32, device=frame.device)
-        s = torch.cuda.current_stream(frame.device)
-        _abi.check(_abi.lib().rtamd_tiles_pack(w, h, C.byref(params), frame.data_ptr(),
-                                               packed.data_ptr(), s.cuda_stream), "rtamd_tiles_pack")
-        return packed
-    own = tiles.pack(frame.numpy(), tw, th, params.tile_first, params.tile_stride)
-    packed = torch.zeros((nmax, th, tw, 4), dtype=torch.float32)
-    packed[: own.shape[0]] = torch.from_numpy(own)
-    return packed
+class FrameGather:
+    """The per-frame exchange with its buffers allocated ONCE: this rank's packed
+    tiles, and on rank 0 one receive buffer per rank.  Every rank pads to the
+    tile count of owner 0 (the largest), so all buffers have one shape."""
+
+    def __init__(self, frame, base_params, rank, world, group=None):
+        h, w, _ = frame.shape
+        self.rank, self.world, self.group = rank, world, group
+        self.base = base_params
+        self.mine_params = owner_params(base_params, rank, world)
+        tw, th = self.mine_params.tile_w or 32, self.mine_params.tile_h or 32
+        self.tile = (tw, th)
+        nmax = tiles.max_owned_count(w, h, tw, th, world)
+        self.cuda = frame.is_cuda
+        # gloo moves host memory: device buffers are staged through the host there (only
+        # used to rehearse the multi-rank path on one GPU; RCCL takes them as they are)
+        self.staged = self.cuda and world > 1 and dist.get_backend(group) == "gloo"
+        shape = (nmax, th, tw, 4)
+        self.packed = torch.zeros(shape, dtype=torch.float32, device=frame.device)
+        self.send = torch.zeros(shape, dtype=torch.float32, pin_memory=True) if self.staged else self.packed
+        self.recv = None
+        self.recv_dev = None
+        if rank == 0 and world > 1:
+            where = "cpu" if self.staged else frame.device
+            self.recv = [torch.zeros(shape, dtype=torch.float32, device=where) for _ in range(world)]
+            if self.staged:
+                self.recv_dev = torch.zeros(shape, dtype=torch.float32, device=frame.device)
+        self.owner = [owner_params(base_params, r, world) for r in range(world)]
+
+    def __call__(self, frame):
+        """Collects every rank's tiles into rank 0's `frame` (in place); `frame` holds
+        this rank's own tiles already."""
+        if self.world == 1:
+            return frame
+        h, w, _ = frame.shape
+        tw, th = self.tile
+        if self.cuda:
+            s = torch.cuda.current_stream(frame.device)
+            _abi.check(_abi.lib().rtamd_tiles_pack(w, h, C.byref(self.mine_params), frame.data_ptr(),
+                                                   self.packed.data_ptr(), s.cuda_stream), "rtamd_tiles_pack")
+            if self.staged:
+                self.send.copy_(self.packed)
+        else:
+            own = tiles.pack(frame.numpy(), tw, th, self.rank, self.world)
+            self.packed[: own.shape[0]] = torch.from_numpy(own)
+        dist.gather(self.send, self.recv, dst=0, group=self.group)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                buf = self.recv[r]
+                if self.staged:
+                    self.recv_dev.copy_(buf)
+                    buf = self.recv_dev
+                _unpack(buf, frame, self.owner[r])
+        return frame
 
 
 def _unpack(packed, frame, params):
@@ -52,30 +91,21 @@ def owner_params(base, rank, world):
     return p
 
 
-def gather_frame(frame, base_params, rank, world, group=None):
+def gather_frame(frame, base_params, rank, world, group=None, gather=None):
     """Collects every rank's tiles into rank 0's `frame` (in place).  `frame` holds
-    this rank's own tiles already.  Returns the frame (complete on rank 0 only)."""
+    this rank's own tiles already.  Returns the frame (complete on rank 0 only).
+    Pass a FrameGather to reuse its buffers from frame to frame."""
     if world == 1:
         return frame
-    mine = _pack(frame, owner_params(base_params, rank, world))
-    # gloo moves host memory: device buffers are staged through the host there
-    # (only used to rehearse the multi-rank path on one GPU; RCCL takes them as they are)
-    staged = mine.is_cuda and dist.get_backend(group) == "gloo"
-    if staged:
-        mine = mine.cpu()
-    bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-    dist.gather(mine, bufs, dst=0, group=group)
-    if rank == 0:
-        for r in range(1, world):
-            buf = bufs[r].to(frame.device) if staged else bufs[r]
-            _unpack(buf, frame, owner_params(base_params, r, world))
-    return frame
+    if gather is None:
+        gather = FrameGather(frame, base_params, rank, world, group=group)
+    return gather(frame)
 
 
-def render_frame(scene, base_params, rank, world, frame=None, want_stats=True, group=None):
+def render_frame(scene, base_params, rank, world, frame=None, want_stats=True, group=None, gather=None):
     """Renders this rank's tiles and gathers the frame on rank 0.
     Returns (frame, stats of this rank)."""
     p = owner_params(base_params, rank, world)
     frame, _, stats = scene.render(p, frame=frame, want_stats=want_stats)
-    gather_frame(frame, base_params, rank, world, group=group)
+    gather_frame(frame, base_params, rank, world, group=group, gather=gather)
     return frame, stats
