@@ -451,43 +451,50 @@ static int import_materials(Import *im, const XmlNode *node)   /* scene.c:258-28
 	return 0;
 }
 
-/* scene.c:284-330.  A requested name matches a light when the light's name
- * starts with it (strncmp over the requested length); the last match wins. */
+/* Index of the LAST light whose name begins with the `len` characters at
+ * `prefix`, or -1.  scene.c:317 compares with strncmp over the requested length
+ * only, so "light" selects "light0", and an empty entry selects the last light. */
+static int light_by_prefix(const Import *im, const char *prefix, size_t len)
+{
+	int found = -1;
+	for (int j = 0; j < im->nlight; j++)
+		if (strncmp(im->light[j].name, prefix, len) == 0)
+			found = j;
+	return found;
+}
+
+/* The `lights=` attribute of <Scene>: comma-separated entries resolved in order
+ * (scene.c:284-330).  As there, the entry count is one more than the number of
+ * commas and is checked before anything is resolved, and the first entry is at
+ * least one character long (a leading comma is part of it). */
 static int import_light_refs(Import *im, const char *names)
 {
-	if (*names == '\0') {
-		im->nscene_lights = 0;
+	im->nscene_lights = 0;
+	if (names[0] == '\0')
 		return 0;
-	}
-	int n = 1;
+	int entries = 1;
 	for (const char *p = names; *p; p++)
-		if (*p == ',')
-			n++;
-	if (n > RTAMD_MAX_LIGHTS) {
-		rtamd_set_error("Too many lights: %d", n);
+		entries += *p == ',';
+	if (entries > RTAMD_MAX_LIGHTS) {
+		rtamd_set_error("Too many lights: %d", entries);
 		return RTAMD_ERR_SCENE;
 	}
-	im->nscene_lights = n;
-	int i = 0;
-	const char *name = names, *end = names;
-	while (*end != '\0') {
-		end++;
-		if (*end == ',' || *end == '\0') {
-			int found = -1;
-			for (int j = 0; j < im->nlight; j++)
-				if (strncmp(im->light[j].name, name, (size_t)(end - name)) == 0)
-					found = j;
-			if (found < 0) {
-				rtamd_set_error("Couldn't find light %d of %s", i, names);
-				return RTAMD_ERR_SCENE;
-			}
-			im->scene_light[i] = im->light[found].light;
-			if (*end == '\0')
-				break;
-			name = end + 1;
-			i++;
+	const char *entry = names;
+	size_t len = 1 + strcspn(names + 1, ",");
+	for (int i = 0; i < entries; i++) {
+		const int j = light_by_prefix(im, entry, len);
+		if (j < 0) {
+			rtamd_set_error("Couldn't find light %d of %s", i, names);
+			return RTAMD_ERR_SCENE;
 		}
+		im->scene_light[i] = im->light[j].light;
+		im->nscene_lights = i + 1;
+		if (entry[len] == '\0')
+			break;
+		entry += len + 1;
+		len = strcspn(entry, ",");
 	}
+	im->nscene_lights = entries;
 	return 0;
 }
 
@@ -521,14 +528,23 @@ static void build_bbox(const Import *im, const NamedShape *shape, rtamd_surface 
 
 	switch (shape->type) {
 	case RTAMD_SHAPE_PLANE: {
-		const double *br = shape->edge1, *tl = shape->edge2;
-		double bl[3] = { 0, 0, 0 }, tr[3] = { br[0] + tl[0], br[1] + tl[1], br[2] + tl[2] };
-		xmin = (float)FMIN(bl[0], FMIN(br[0], FMIN(tl[0], tr[0])));
-		ymin = (float)FMIN(bl[1], FMIN(br[1], FMIN(tl[1], tr[1])));
-		zmin = (float)FMIN(bl[2], FMIN(br[2], FMIN(tl[2], tr[2])));
-		xmax = (float)FMAX(bl[0], FMAX(br[0], FMAX(tl[0], tr[0])));
-		ymax = (float)FMAX(bl[1], FMAX(br[1], FMAX(tl[1], tr[1])));
-		zmax = (float)FMAX(bl[2], FMAX(br[2], FMAX(tl[2], tr[2])));
+		/* the parallelogram's corners 0, e1, e2, e1 + e2 (scene.c:465-478); the
+		 * extremes are folded from the last corner to the first, the nesting of the
+		 * reference's MIN / MAX macros */
+		const double *e1 = shape->edge1, *e2 = shape->edge2;
+		float lo[3], hi[3];
+		for (int a = 0; a < 3; a++) {
+			const double corner[4] = { 0.0, e1[a], e2[a], e1[a] + e2[a] };
+			double mn = corner[3], mx = corner[3];
+			for (int c = 2; c >= 0; c--) {
+				mn = FMIN(corner[c], mn);
+				mx = FMAX(corner[c], mx);
+			}
+			lo[a] = (float)mn;
+			hi[a] = (float)mx;
+		}
+		xmin = lo[0]; ymin = lo[1]; zmin = lo[2];
+		xmax = hi[0]; ymax = hi[1]; zmax = hi[2];
 		break;
 	}
 	case RTAMD_SHAPE_DISK:

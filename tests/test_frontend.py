@@ -296,3 +296,109 @@ def test_blob_validation_rejects_corruption():
     bad[off:off + 4] = struct.pack("<i", 10 ** 6)
     with pytest.raises(_abi.RtamdError):
         ra.SceneBlob(bytes(bad))
+
+
+# ---- the stochastic scenes' fields, derived by hand from the scene files ---------
+#
+# No output of the reference's own front end exists for 6-soft / 7-reflections /
+# 8-glossy / showcase (its OBJ reader cannot be generated here), so what their
+# images depend on - area lights, glossiness, the boxes of disks and cylinders - is
+# asserted against values worked out from the .sdl text and the rules of
+# scene.c:78-91 (config), :140-186 (lights), :262-282 (materials), :458-526 (boxes).
+
+def f32(x):
+    return float(np.float32(x))
+
+
+def obj_vertex_bounds(name):
+    v = np.array([[np.float32(t) for t in line.split()[1:4]] for line in open(os.path.join(ASSETS, name))
+                  if line.startswith("v ")], np.float32)
+    return v.min(axis=0), v.max(axis=0)
+
+
+def light_tuple(l):
+    return (l.type, l.intensity, tuple(l.position), tuple(l.edge1), tuple(l.edge2), tuple(l.colour)[:3])
+
+
+def test_glossy_and_reflection_scene_fields_by_hand():
+    for name, gloss in (("8-glossy", f32(0.3)), ("7-reflections", 0.0)):
+        b = ra.load_sdl(scene_path(name))
+        h = b.header
+        assert (h.width, h.height, h.antialiasing, h.aa_samples) == (640, 640, 1, 5)
+        assert (h.shadow_samples, h.reflection_samples, h.max_reflections) == (5, 8, 5)
+        assert h.has_cubemap == 1 and [round(c, 6) for c in list(h.background)[:3]] == [0.3, 0.3, 0.3]
+        # lights="light0,backlight": two area lights, in that order (the point light and the
+        # two other area lights of the file are not referenced)
+        assert [light_tuple(l) for l in b.lights] == [
+            (_abi.LIGHT_AREA, f32(0.9), (0.0, 8.0, 8.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (1.0, 1.0, 1.0)),
+            (_abi.LIGHT_AREA, f32(0.6), (0.0, 8.0, -8.0), (1.0, 0.0, 0.0), (0.0, 0.0, 3.0), (1.0, 1.0, 1.0))]
+        # traversal order is reverse document order: disk, sphere, teapot, cylinder
+        s = b.surfaces
+        assert [x.shape_type for x in s] == [_abi.SHAPE_DISK, _abi.SHAPE_SPHERE, _abi.SHAPE_MESH, _abi.SHAPE_CYLINDER]
+        mats = b.materials
+        names = [mats[x.material] for x in s]
+        green = names[2]
+        assert (green.shininess, green.reflect, green.glossiness) == (400, 0.5, gloss)
+        assert [round(c, 6) for c in list(green.diffuse)[:3]] == [0.22, 0.88, 0.44]
+        for other in (names[0], names[1], names[3]):
+            assert (other.shininess, other.reflect, other.glossiness) == (400, 0.0, 0.0)
+        # disk r = 6 rotated 90 deg about x: model (x, y, z) -> world (x, -z, y); model box
+        # +-(6 + 1e-3) in x, y and +-2e-3 in z (1e-3 thick, grown by 1e-3)
+        assert s[0].radius == 6.0
+        np.testing.assert_allclose(list(s[0].bbox), [-6.001, -0.002, -6.001, 6.001, 0.002, 6.001], atol=2e-6)
+        # sphere r = 1 at (-2, 1, 4)
+        np.testing.assert_allclose(list(s[1].bbox), [-3.001, -0.001, 2.999, -0.999, 2.001, 5.001], atol=2e-6)
+        # teapot under the identity: the box of its vertices, not grown
+        lo, hi = obj_vertex_bounds("teapot.obj")
+        assert list(s[2].bbox) == [float(x) for x in lo] + [float(x) for x in hi]
+        # cylinder r = 1, h = 2, capped, rotated 90 deg about x then moved to (2.4, 1.99, 4.4):
+        # world x = mx + 2.4, y = 1.99 - mz, z = my + 4.4 with mx, my in +-1.001, mz in [-0.001, 2.001]
+        assert (s[3].radius, s[3].height, s[3].capped) == (1.0, 2.0, 1)
+        np.testing.assert_allclose(list(s[3].bbox), [1.399, -0.011, 3.399, 3.401, 1.991, 5.401], atol=3e-6)
+        assert not b.fixed_rng_consumption()
+
+
+def test_soft_shadow_scene_fields_by_hand():
+    b = ra.load_sdl(scene_path("6-soft"))
+    h = b.header
+    assert (h.width, h.height, h.antialiasing, h.aa_samples) == (1024, 512, 1, 4)
+    assert (h.shadow_samples, h.reflection_samples, h.max_reflections) == (4, 10, 5)
+    assert h.has_cubemap == 0 and h.cam_fov == 90.0
+    # three area lights of intensity 1 (DTD default); the blue one has a zero edge2
+    assert [light_tuple(l) for l in b.lights] == [
+        (_abi.LIGHT_AREA, 1.0, (-5.0, 5.0, 4.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 0.0)),
+        (_abi.LIGHT_AREA, 1.0, (0.0, 5.0, 4.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0)),
+        (_abi.LIGHT_AREA, 1.0, (5.0, 5.0, 4.0), (1.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0))]
+    s = b.surfaces
+    # only the teapot and the disk are placed (sphere, cylinder and cone are defined, not used)
+    assert [x.shape_type for x in s] == [_abi.SHAPE_DISK, _abi.SHAPE_MESH]
+    assert s[0].radius == 40.0
+    # disk r = 40 moved to z = -4, not rotated: it lies in the plane z = -4
+    np.testing.assert_allclose(list(s[0].bbox), [-40.001, -40.001, -4.002, 40.001, 40.001, -3.998], atol=8e-6)
+    green = b.materials[s[1].material]
+    assert (green.shininess, green.reflect, green.glossiness) == (400, 0.0, 0.0)
+
+
+def test_showcase_scene_fields_by_hand():
+    b = ra.load_sdl(scene_path("showcase-uffizi"))
+    h = b.header
+    assert (h.width, h.height, h.antialiasing, h.shadow_samples, h.reflection_samples) == (512, 512, 0, 4, 2)
+    # lights="light0,camlight": the point light, then the area light at the camera
+    assert [light_tuple(l) for l in b.lights] == [
+        (_abi.LIGHT_POINT, f32(0.9), (0.0, 10.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),
+        (_abi.LIGHT_AREA, 0.5, (0.0, 10.0, 10.0), (0.0, 0.0, 2.0), (2.0, 0.0, 0.0), (1.0, 1.0, 1.0))]
+    s = b.surfaces
+    # reverse document order: cylinder, teapot, sphere, tablecloth (table.obj is never placed
+    # and does not reach the blob)
+    assert [x.shape_type for x in s] == [_abi.SHAPE_CYLINDER, _abi.SHAPE_MESH, _abi.SHAPE_SPHERE, _abi.SHAPE_MESH]
+    assert b.header.num_meshes == 2
+    # cylinder rotated -90 deg about x: model (x, y, z) -> world (x, z, -y), then moved to (3, 7.3, -3)
+    np.testing.assert_allclose(list(s[0].bbox), [1.999, 7.299, -4.001, 4.001, 9.301, -1.999], atol=3e-6)
+    # teapot lifted by 7.3 under a unit scale; tablecloth under the identity
+    lo, hi = obj_vertex_bounds("teapot.obj")
+    np.testing.assert_allclose(list(s[1].bbox), list(lo + np.float32([0, 7.3, 0])) + list(hi + np.float32([0, 7.3, 0])),
+                               atol=2e-6)
+    np.testing.assert_allclose(list(s[2].bbox), [-4.001, 7.299, 1.999, -1.999, 9.301, 4.001], atol=3e-6)
+    lo, hi = obj_vertex_bounds("tablecloth.obj")
+    assert list(s[3].bbox) == [float(x) for x in lo] + [float(x) for x in hi]
+    assert all((m.reflect, m.glossiness) == (0.0, 0.0) for m in b.materials)
