@@ -42,7 +42,7 @@ enum rtamd_status {
  * Scene blob layout.  Offsets are bytes from the start of the blob.
  * ------------------------------------------------------------------------ */
 
-#define RTAMD_BLOB_MAGIC 0x314353444d415452ull /* "RTAMDSC1" */
+#define RTAMD_BLOB_MAGIC 0x324353444d415452ull /* "RTAMDSC2" */
 #define RTAMD_MAX_LIGHTS 8                     /* scene.h:10 */
 
 enum rtamd_shape_type {          /* scene.h:47-48, same numbering */
@@ -99,6 +99,8 @@ typedef struct rtamd_mesh {       /* mesh.h:18-36 */
 	uint64_t off_vertex;          /* double[3*num_vertices] (float-valued, mesh.c:93-95) */
 	uint64_t off_normal;          /* double[3*num_normals]; 0 when the OBJ has no vn */
 	uint64_t off_triangle;        /* int32[6*num_triangles]: v0 v1 v2 n0 n1 n2, 0-based */
+	uint64_t off_name;            /* NUL-terminated name of the <Mesh> shape (Shape.name,
+	                               * scene.h:57; printed by scene.c:662); 0 = unnamed */
 } rtamd_mesh;
 
 typedef struct rtamd_cubemap {    /* texture.h:14-22 */
@@ -147,6 +149,12 @@ typedef struct rtamd_blob_header {
 int rtamd_sdl_load(const char *sdl_path, const char *asset_dir,
 		void **blob, size_t *blob_size);
 void rtamd_blob_free(void *blob);
+
+/* The reference's loader prints "Loading cubemap took ..." while it runs
+ * (scene.c:570-573).  This returns the time the last rtamd_sdl_load of the
+ * calling thread spent loading the cubemap, in seconds, or a negative value if
+ * that scene has none, so that a driver can print the same line. */
+double rtamd_last_cubemap_load_seconds(void);
 
 /* Structural validation of a blob (bounds of every offset and index). */
 int rtamd_blob_validate(const void *blob, size_t blob_size);
@@ -287,6 +295,9 @@ int rtamd_tiles_unpack(int width, int height, const rtamd_render_params *params,
 		const void *d_packed, void *d_frame, void *stream);
 
 /* Host-side query helpers. */
+/* Seconds rtamd_scene_create spent on mesh `mesh`'s acceleration structure (the
+ * figure behind the reference's "Building kd-tree took ..." line, scene.c:663-666). */
+int rtamd_scene_mesh_build_seconds(const rtamd_scene *scene, int mesh, double *seconds);
 int rtamd_scene_dims(const rtamd_scene *scene, int *width, int *height, int *spp);
 const char *rtamd_last_error(void);
 const char *rtamd_version(void);

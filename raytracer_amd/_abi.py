@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTAMD_LIB selects another build of the same library (A/B measurements).
 LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "csrc", "librtamd.so")
 
-RTAMD_BLOB_MAGIC = 0x314353444D415452
+RTAMD_BLOB_MAGIC = 0x324353444D415452
 RTAMD_MAX_LIGHTS = 8
 
 SHAPE_PLANE, SHAPE_DISK, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_CONE, SHAPE_MESH = range(6)
@@ -50,7 +50,7 @@ class Mesh(C.Structure):
     _fields_ = [("num_vertices", C.c_int32), ("num_normals", C.c_int32),
                 ("num_triangles", C.c_int32), ("pad", C.c_int32),
                 ("off_vertex", C.c_uint64), ("off_normal", C.c_uint64),
-                ("off_triangle", C.c_uint64)]
+                ("off_triangle", C.c_uint64), ("off_name", C.c_uint64)]
 
 
 class Cubemap(C.Structure):
@@ -123,6 +123,8 @@ PROTOTYPES = {
                                    C.c_void_p, C.c_void_p]),
     "rtamd_tiles_unpack": (C.c_int, [C.c_int, C.c_int, C.POINTER(RenderParams), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "rtamd_last_cubemap_load_seconds": (C.c_double, []),
+    "rtamd_scene_mesh_build_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "rtamd_scene_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int)]),
     "rtamd_last_error": (C.c_char_p, []),

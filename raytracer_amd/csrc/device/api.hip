@@ -2,6 +2,7 @@
 // upload, and the host-side orchestration of the render pipeline.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,7 @@ struct rtamd_scene {
 	unsigned bounce_capacity = 0;
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	int device = -1;             // the device the scene's buffers live on
+	std::vector<double> mesh_build_seconds;
 	unsigned queue_capacity_max = 0;
 	unsigned overflow_test_capacity = 0;
 	// queue-overflow count of the last asynchronous render, in host-visible memory
@@ -151,6 +153,8 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 {
 	if (!sc)
 		return 0;
+	if (sc->device >= 0)
+		(void)hipSetDevice(sc->device);
 	for (void *p : sc->allocations)
 		(void)hipFree(p);
 	if (sc->d_glibc) (void)hipFree(sc->d_glibc);
@@ -331,7 +335,11 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 				for (int a = 0; a < 3; a++)
 					pos[9 * (size_t)i + 3 * c + a] = (float)v[3 * (size_t)t[6 * i + c] + a];
 		BvhResult bvh;
-		if (!bvh_build_mesh(pos.data(), nt, bvh)) {
+		const auto build_t0 = std::chrono::steady_clock::now();
+		const bool built = bvh_build_mesh(pos.data(), nt, bvh);
+		sc->mesh_build_seconds.push_back(
+				std::chrono::duration<double>(std::chrono::steady_clock::now() - build_t0).count());
+		if (!built) {
 			rtamd_set_error("mesh %d: could not build a BVH within the traversal stack depth", m);
 			return RTAMD_ERR_LIMIT;
 		}
@@ -434,6 +442,12 @@ extern "C" int rtamd_scene_create(const void *blob, size_t blob_size, rtamd_scen
 	if (rc)
 		return rc;
 	rtamd_scene *sc = new rtamd_scene();
+	sc->device = g_device;
+	if (hipSetDevice(g_device) != hipSuccess) {
+		rtamd_set_error("rtamd_scene_create: cannot select device %d", g_device);
+		delete sc;
+		return RTAMD_ERR_HIP;
+	}
 	std::memcpy(&sc->header, blob, sizeof sc->header);
 	if (sc->header.max_reflections > 60) {
 		rtamd_set_error("max_reflections %d exceeds the limit of 60", sc->header.max_reflections);
@@ -446,6 +460,16 @@ extern "C" int rtamd_scene_create(const void *blob, size_t blob_size, rtamd_scen
 		return rc;
 	}
 	*scene = sc;
+	return 0;
+}
+
+extern "C" int rtamd_scene_mesh_build_seconds(const rtamd_scene *sc, int mesh, double *seconds)
+{
+	if (!sc || !seconds || mesh < 0 || mesh >= (int)sc->mesh_build_seconds.size()) {
+		rtamd_set_error("rtamd_scene_mesh_build_seconds: bad argument");
+		return RTAMD_ERR_ARG;
+	}
+	*seconds = sc->mesh_build_seconds[mesh];
 	return 0;
 }
 
@@ -574,13 +598,22 @@ static int take_sticky_overflow(rtamd_scene *sc)
 	return 0;
 }
 
+// Renders the pixels [pix_lo, pix_hi) of the owner's tile sequence (whole tiles: the
+// run of owned tiles the call's window can touch).  w.accum holds one slot per pixel
+// of that run; the kernels index accumulators by position in the whole sequence, so
+// they get the pointer moved back by the run's start.
 static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const RenderWork &w, bool direct,
-		unsigned long long pixels, void *d_colour, void *d_hits, rtamd_render_stats *stats, hipStream_t stream)
+		unsigned long long pix_lo, unsigned long long pix_hi, void *d_colour, void *d_hits,
+		rtamd_render_stats *stats, hipStream_t stream)
 {
 	const DevScene &dev = sc->dev;
-	const unsigned long long samples = pixels * (unsigned)dev.spp;
+	const unsigned long long pixels = pix_hi - pix_lo;
+	const unsigned long long sample_lo = pix_lo * (unsigned)dev.spp, samples = pix_hi * (unsigned)dev.spp;
+	long long *const accum = w.accum ? w.accum - 3 * (long long)pix_lo : nullptr;
 	const unsigned long long fan = queue_fan(sc);
-	unsigned long long chunk = samples;
+	unsigned long long chunk = samples - sample_lo;
+	if (!chunk)
+		chunk = RT_BLOCK;
 	if (dev.any_reflective) {
 		chunk = w.queue_capacity / fan;
 		chunk -= chunk % RT_BLOCK;
@@ -616,7 +649,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 		unsigned long long blocks = ((unsigned long long)w.queue_capacity + RT_BLOCK - 1) / RT_BLOCK;
 		bounce_grid = blocks > 2048 ? 2048u : (unsigned)blocks;
 	}
-	for (unsigned long long first = 0; first < samples; first += chunk) {
+	for (unsigned long long first = sample_lo; first < samples; first += chunk) {
 		unsigned long long count = samples - first < chunk ? samples - first : chunk;
 		if (levels)
 			HIP_TRY(hipMemsetAsync(w.qcount, 0, sizeof(unsigned) * 128, stream));
@@ -627,7 +660,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 			ev.chunks.push_back(e);
 			HIP_TRY(hipEventRecord(e, stream));
 		}
-		HIP_TRY(rt_launch_primary(dev, p, first, count, w.glibc, w.accum,
+		HIP_TRY(rt_launch_primary(dev, p, first, count, w.glibc, accum,
 				direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits),
 				levels ? w.queue[0] : nullptr, levels ? w.qcount : nullptr, kernel_capacity, w.counters, stream));
 		if (timed) {
@@ -641,18 +674,18 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 			// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
 			if (w.bounce.hits)
 				HIP_TRY(rt_launch_bounce_sorted(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
-						kernel_capacity, w.accum, level < levels ? w.queue[level & 1] : nullptr,
+						kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
 						w.qcount + level, w.counters, w.bounce, bounce_grid, stream));
 			else
 				HIP_TRY(rt_launch_bounce(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
-						kernel_capacity, w.accum, level < levels ? w.queue[level & 1] : nullptr,
+						kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
 						w.qcount + level, w.counters, bounce_grid, stream));
 			launches_bounce++;
 		}
 	}
 	HIP_TRY(rt_launch_collect_stats(w.counters, stream));
 	if (!direct)
-		HIP_TRY(rt_launch_resolve(dev, p, 0, pixels, w.accum, static_cast<float *>(d_colour), w.counters,
+		HIP_TRY(rt_launch_resolve(dev, p, pix_lo, pixels, accum, static_cast<float *>(d_colour), w.counters,
 				sc->d_overflow, stream));
 
 	if (stats) {
@@ -679,7 +712,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 		stats->queue_peak = c.queue_peak;
 		stats->bvh_nodes = c.bvh_nodes;
 		stats->tri_tests = c.tri_tests;
-		stats->samples = samples;
+		stats->samples = samples - sample_lo;
 		stats->launches_primary = launches_primary;
 		stats->launches_bounce = launches_bounce;
 		if (c.queue_overflow) {
@@ -693,13 +726,26 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 }
 
 // Argument checks shared by the two render entry points.
+// One process may hold scenes on several GPUs (rtamd_init once per device): every
+// entry point that launches work makes the scene's device current first.
+static int use_scene_device(const rtamd_scene *sc)
+{
+	int current = -1;
+	HIP_TRY(hipGetDevice(&current));
+	if (current != sc->device)
+		HIP_TRY(hipSetDevice(sc->device));
+	return 0;
+}
+
 static int render_prepare(rtamd_scene *sc, const rtamd_render_params *params, void *d_colour, void *d_hits,
-		rtamd_render_params *p, unsigned long long *pixels, bool *direct)
+		rtamd_render_params *p, unsigned long long *pix_lo, unsigned long long *pix_hi, bool *direct)
 {
 	if (!sc || !d_colour) {
 		rtamd_set_error("rtamd_render: NULL scene or output");
 		return RTAMD_ERR_ARG;
 	}
+	if (int rc0 = use_scene_device(sc))
+		return rc0;
 	int rc = take_sticky_overflow(sc);
 	if (rc)
 		return rc;
@@ -714,11 +760,15 @@ static int render_prepare(rtamd_scene *sc, const rtamd_render_params *params, vo
 		rtamd_set_error("hit records are only available for single-owner renders (tile_stride 1)");
 		return RTAMD_ERR_ARG;
 	}
-	*pixels = rt_owned_pixels(sc->dev.width, sc->dev.height, *p);
-	if (*pixels > 0xffffffffull) {
+	if (rt_owned_pixels(sc->dev.width, sc->dev.height, *p) > 0xffffffffull) {
 		rtamd_set_error("too many pixels per call");
 		return RTAMD_ERR_LIMIT;
 	}
+	unsigned long long tile_lo, tile_hi;
+	rt_window_tile_range(sc->dev.width, sc->dev.height, *p, &tile_lo, &tile_hi);
+	const unsigned long long per_tile = (unsigned long long)p->tile_w * (unsigned)p->tile_h;
+	*pix_lo = tile_lo * per_tile;
+	*pix_hi = tile_hi * per_tile;
 	// Without reflections, and with all samples of a pixel inside one wave, the
 	// primary kernel writes finished pixels itself: no accumulators, no resolve.
 	*direct = !sc->dev.any_reflective && 64 % sc->dev.spp == 0;
@@ -730,11 +780,12 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 {
 	hipStream_t stream = static_cast<hipStream_t>(stream_v);
 	rtamd_render_params p;
-	unsigned long long pixels = 0;
+	unsigned long long pix_lo = 0, pix_hi = 0;
 	bool direct = false;
-	int rc = render_prepare(sc, params, d_colour, d_hits, &p, &pixels, &direct);
+	int rc = render_prepare(sc, params, d_colour, d_hits, &p, &pix_lo, &pix_hi, &direct);
 	if (rc)
 		return rc;
+	const unsigned long long pixels = pix_hi - pix_lo;
 	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
 		return rc;
 	const DevScene &dev = sc->dev;
@@ -797,7 +848,7 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 	if (!sc->sorted_bounce)
 		w.bounce.hits = nullptr;
 	w.glibc = sc->d_glibc;
-	return render_impl(sc, p, w, direct, pixels, d_colour, d_hits, stats, stream);
+	return render_impl(sc, p, w, direct, pix_lo, pix_hi, d_colour, d_hits, stats, stream);
 }
 
 // ---- the entry point that allocates nothing ------------------------------------
@@ -837,11 +888,12 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 {
 	hipStream_t stream = static_cast<hipStream_t>(stream_v);
 	rtamd_render_params p;
-	unsigned long long pixels = 0;
+	unsigned long long pix_lo = 0, pix_hi = 0;
 	bool direct = false;
-	int rc = render_prepare(sc, params, d_colour, nullptr, &p, &pixels, &direct);
+	int rc = render_prepare(sc, params, d_colour, nullptr, &p, &pix_lo, &pix_hi, &direct);
 	if (rc)
 		return rc;
+	const unsigned long long pixels = pix_hi - pix_lo;
 	if (p.rng_mode == RTAMD_RNG_GLIBC && sc->dev.antialiasing) {
 		rtamd_set_error("rtamd_render_noalloc: RTAMD_RNG_GLIBC with antialiasing needs a table of the rand() "
 				"stream, which this entry point does not allocate; use RTAMD_RNG_KEYED or rtamd_render");
@@ -910,7 +962,7 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		return RTAMD_ERR_LIMIT;
 	}
 	w.glibc = nullptr;
-	return render_impl(sc, p, w, direct, pixels, d_colour, nullptr, nullptr, stream);
+	return render_impl(sc, p, w, direct, pix_lo, pix_hi, d_colour, nullptr, nullptr, stream);
 }
 
 extern "C" int rtamd_trace(rtamd_scene *sc, const void *d_rays, uint64_t n, void *d_hits, void *stream_v)
@@ -923,6 +975,8 @@ extern "C" int rtamd_trace(rtamd_scene *sc, const void *d_rays, uint64_t n, void
 		rtamd_set_error("rtamd_trace: too many rays in one call");
 		return RTAMD_ERR_LIMIT;
 	}
+	if (int rc0 = use_scene_device(sc))
+		return rc0;
 	HIP_TRY(rt_launch_trace(sc->dev, static_cast<const double *>(d_rays), n,
 			static_cast<rtamd_hit_record *>(d_hits), static_cast<hipStream_t>(stream_v)));
 	return 0;
@@ -938,6 +992,8 @@ extern "C" int rtamd_camera_rays(rtamd_scene *sc, const rtamd_render_params *par
 	rtamd_render_params p;
 	int rc = normalise_params(sc->dev.width, sc->dev.height, params, &p);
 	if (rc)
+		return rc;
+	if ((rc = use_scene_device(sc)))
 		return rc;
 	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
 		return rc;

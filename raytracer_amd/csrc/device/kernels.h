@@ -7,6 +7,8 @@
 
 int rt_tiles_owned(int width, int height, const rtamd_render_params &p);
 unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_params &p);
+void rt_window_tile_range(int width, int height, const rtamd_render_params &p, unsigned long long *lo,
+		unsigned long long *hi);
 
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,

@@ -797,6 +797,24 @@ unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_par
 	return (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h);
 }
 
+// The owned tiles that a call's pixel window can touch: positions [lo, hi) in the
+// owner's tile sequence (tiles are numbered row by row, so the tile rows a window
+// spans are one contiguous run of tile numbers).  The whole frame: [0, owned).
+void rt_window_tile_range(int width, int height, const rtamd_render_params &p, unsigned long long *lo,
+		unsigned long long *hi)
+{
+	const TileMap tm = make_tile_map(width, height, p);
+	const long long t0 = (long long)(tm.y0 / tm.tile_h) * tm.tiles_x;
+	const long long t1 = (long long)((tm.y1 - 1) / tm.tile_h + 1) * tm.tiles_x;
+	auto position = [&](long long tile) {
+		// number of owned tiles below `tile`: ceil((tile - first) / stride), within [0, owned]
+		long long n = tile <= tm.tile_first ? 0 : (tile - tm.tile_first + tm.tile_stride - 1) / tm.tile_stride;
+		return (unsigned long long)(n > tm.owned ? tm.owned : n);
+	};
+	*lo = position(t0);
+	*hi = position(t1);
+}
+
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
 		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,

@@ -59,6 +59,11 @@ int rtamd_blob_validate(const void *blob, size_t blob_size)
 			rtamd_set_error("scene blob: mesh %d arrays out of bounds", m);
 			return RTAMD_ERR_ARG;
 		}
+		if (d->off_name && (d->off_name >= blob_size ||
+				!memchr(base + d->off_name, 0, blob_size - d->off_name))) {
+			rtamd_set_error("scene blob: mesh %d name is not terminated inside the blob", m);
+			return RTAMD_ERR_ARG;
+		}
 		const int32_t *tri = (const int32_t *)(base + d->off_triangle);
 		for (int64_t t = 0; t < d->num_triangles; t++)
 			for (int c = 0; c < 3; c++) {

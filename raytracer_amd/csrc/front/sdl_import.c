@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "front.h"
 #include "xml_mini.h"
@@ -290,8 +291,23 @@ typedef struct Import {
 	int nmesh; FrontMesh *meshes;
 	int nscene_lights; rtamd_light scene_light[RTAMD_MAX_LIGHTS];
 	int has_cubemap; CubeFace face[6];
+	double cubemap_seconds;
 	int nsurf, capsurf; rtamd_surface *surf;   /* in DOCUMENT order; reversed when packed */
 } Import;
+
+static __thread double t_cubemap_seconds = -1.0;
+
+double rtamd_last_cubemap_load_seconds(void)
+{
+	return t_cubemap_seconds;
+}
+
+static double wall_seconds(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static char *dupstr(const char *s)
 {
@@ -765,7 +781,9 @@ static int import_scene(Import *im, const XmlNode *node)   /* scene.c:528-597 */
 	parse_colour(get_prop(node, "background"), im->hdr.background);
 	const char *cubemap = get_prop(node, "cubemap");
 	if (cubemap[0] != '\0') {
+		const double t0 = wall_seconds();
 		rc = load_cubemap(im, cubemap);
+		im->cubemap_seconds = wall_seconds() - t0;
 		if (rc)
 			return rc;
 	}
@@ -790,6 +808,15 @@ static int import_scene(Import *im, const XmlNode *node)   /* scene.c:528-597 */
 static size_t align8(size_t x)
 {
 	return (x + 7u) & ~(size_t)7u;
+}
+
+/* Name of the <Mesh> shape that loaded front mesh `mesh` (the first, if several do). */
+static const char *mesh_shape_name(const Import *im, int mesh)
+{
+	for (int i = 0; i < im->nshape; i++)
+		if (im->shape[i].type == RTAMD_SHAPE_MESH && im->shape[i].mesh == mesh)
+			return im->shape[i].name;
+	return "";
 }
 
 static int pack_blob(Import *im, void **blob_out, size_t *size_out)
@@ -827,6 +854,7 @@ static int pack_blob(Import *im, void **blob_out, size_t *size_out)
 			off = align8(off + sizeof(double) * 3 * (size_t)fm->num_normals);
 		}
 		d->off_triangle = off; off = align8(off + sizeof(int32_t) * 6 * (size_t)fm->num_triangles);
+		d->off_name = off;     off = align8(off + strlen(mesh_shape_name(im, i)) + 1);
 	}
 	rtamd_cubemap cube;
 	memset(&cube, 0, sizeof cube);
@@ -882,6 +910,7 @@ static int pack_blob(Import *im, void **blob_out, size_t *size_out)
 					sizeof(double) * 3 * (size_t)fm->num_normals);
 		memcpy(blob + d->off_triangle, fm->triangle,
 				sizeof(int32_t) * 6 * (size_t)fm->num_triangles);
+		strcpy((char *)blob + d->off_name, mesh_shape_name(im, i));
 	}
 	if (im->has_cubemap) {
 		memcpy(blob + off_cube, &cube, sizeof cube);
@@ -954,6 +983,7 @@ int rtamd_sdl_load(const char *sdl_path, const char *asset_dir, void **blob, siz
 	Import im;
 	memset(&im, 0, sizeof im);
 	im.asset_dir = asset_dir;
+	im.cubemap_seconds = -1.0;
 	int rc = 0;
 	/* scene.c:610-652 */
 	for (const XmlNode *node = root->first_child; node && !rc; node = node->next) {
@@ -983,6 +1013,7 @@ int rtamd_sdl_load(const char *sdl_path, const char *asset_dir, void **blob, siz
 	}
 	if (!rc)
 		rc = pack_blob(&im, blob, blob_size);
+	t_cubemap_seconds = im.cubemap_seconds;
 	import_free(&im);
 	xml_free(root);
 	return rc;

@@ -30,7 +30,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_abi.Light) == 96
     assert C.sizeof(_abi.Material) == 48
     assert C.sizeof(_abi.Surface) == 16 + 48 + 8 + 256 + 24
-    assert C.sizeof(_abi.Mesh) == 40
+    assert C.sizeof(_abi.Mesh) == 48
     assert C.sizeof(_abi.Cubemap) == 96
     assert C.sizeof(_abi.RenderParams) == 48
 

@@ -42,3 +42,70 @@ def test_cli_error_paths(tmp_path):
     r = subprocess.run([CLI, "does-not-exist.sdl"], cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and r.stdout.strip() != ""
     assert not os.path.exists(os.path.join(str(tmp_path), "ray.ppm"))
+
+
+def run_cli(tmp_path, *args):
+    return subprocess.run([CLI, *args], cwd=str(tmp_path), capture_output=True, text=True, timeout=200)
+
+
+def read_ppm(path):
+    import numpy as np
+    data = open(path, "rb").read()
+    magic, dims, maxval, rest = data.split(b"\n", 3)
+    w, h = (int(x) for x in dims.split())
+    assert magic == b"P6" and maxval == b"255"
+    return np.frombuffer(rest, np.uint8).reshape(h, w, 3)
+
+
+def test_console_lines_are_the_references(tmp_path):
+    """scene.c:570-573 (cubemap), :662-666 (one kd-tree per mesh, named, in the order
+    the surface walk meets them), raytracer.c:13-30,83-92 (bar, timing lines)."""
+    import re
+    r = run_cli(tmp_path, os.path.join(ASSETS, "showcase-uffizi.sdl"), "--assets", ASSETS, "--width", "128",
+                "--height", "96")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.replace("\r", "\n").split("\n")
+    text = [l for l in lines if l and not l.startswith("[")]
+    took = r"took \d+ s \d{3} msec$"
+    assert re.match(r"Loading cubemap " + took, text[0])
+    # traversal order is reverse document order: the teapot is met before the tablecloth
+    assert text[1] == "Building kd-tree for teapot" and re.match("Building kd-tree " + took, text[2])
+    assert text[3] == "Building kd-tree for tablecloth" and re.match("Building kd-tree " + took, text[4])
+    assert re.match("Rendering " + took, text[5])
+    assert re.match(r"\d+\.\d\d kilopixels per second$", text[6])
+    assert len(text) == 7
+    bars = [l for l in lines if l.startswith("[")]
+    assert bars and all(len(b) == 73 for b in bars)            # '[' + 70 + '>' ... + ']'
+    assert bars[-1] == "[" + "=" * 70 + ">]"
+    # without a cubemap there is no cubemap line; --stats adds the ray line at the end
+    r = run_cli(tmp_path, os.path.join(ASSETS, "6-soft.sdl"), "--assets", ASSETS, "--width", "64", "--height", "32",
+                "--stats")
+    text = [l for l in r.stdout.replace("\r", "\n").split("\n") if l and not l.startswith("[")]
+    assert text[0] == "Building kd-tree for teapot" and "Loading cubemap" not in r.stdout
+    assert re.match(r"\d+ rays, ", text[-1])
+
+
+def test_overrides_bands_and_devices(tmp_path):
+    """--width/--height/--aa/--seed/-o change what they name; the number of bands and
+    the list of devices (two "devices" that are the same GPU here) change nothing."""
+    import numpy as np
+    scene = os.path.join(ASSETS, "7-reflections.sdl")
+    base = ["--assets", ASSETS, "--width", "96", "--height", "80", "--aa", "2"]
+    r = run_cli(tmp_path, scene, *base, "-o", "a.ppm")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert not os.path.exists(os.path.join(str(tmp_path), "ray.ppm"))
+    a = read_ppm(os.path.join(str(tmp_path), "a.ppm"))
+    assert a.shape == (80, 96, 3) and a.max() > 50
+    for extra, name in ((["--bands", "1"], "b.ppm"), (["--bands", "3"], "c.ppm"),
+                        (["--devices", "0,0"], "d.ppm"), (["--devices", "0,0,0", "--bands", "2"], "e.ppm")):
+        r = run_cli(tmp_path, scene, *base, *extra, "-o", name)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(read_ppm(os.path.join(str(tmp_path), name)), a), extra
+    r = run_cli(tmp_path, scene, *base, "--seed", "12345", "-o", "s.ppm")
+    s = read_ppm(os.path.join(str(tmp_path), "s.ppm"))
+    assert s.shape == a.shape and not np.array_equal(s, a)
+    assert np.abs(s.astype(int) - a.astype(int)).mean() < 3.0      # another sample set, the same picture
+    r = run_cli(tmp_path, scene, *base[:-2], "--no-aa", "-o", "n.ppm")
+    assert r.returncode == 0 and not np.array_equal(read_ppm(os.path.join(str(tmp_path), "n.ppm")), a)
+    assert run_cli(tmp_path, scene, "--frobnicate").returncode == 1
+    assert run_cli(tmp_path, scene, *base, "--device", "99").returncode == 1
