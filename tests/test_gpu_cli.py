@@ -109,3 +109,25 @@ def test_overrides_bands_and_devices(tmp_path):
     assert r.returncode == 0 and not np.array_equal(read_ppm(os.path.join(str(tmp_path), "n.ppm")), a)
     assert run_cli(tmp_path, scene, "--frobnicate").returncode == 1
     assert run_cli(tmp_path, scene, *base, "--device", "99").returncode == 1
+
+
+def test_progressive_viewer_fills_in_and_ends_on_the_batch_frame(tmp_path):
+    """rayviewer (rayviewer.c:91-174 without the window): refreshes by interleaved tile
+    subsets in a shuffled order; every refresh adds pixels, and the frame it leaves in
+    ray.ppm is the batch driver's frame without antialiasing, whatever the pass count."""
+    import numpy as np
+    viewer = os.path.join(ROOT, "raytracer_amd", "csrc", "rayviewer")
+    scene = os.path.join(ASSETS, "7-reflections.sdl")
+    r = subprocess.run([CLI, scene, "--assets", ASSETS, "--no-aa", "--rng", "keyed", "-o", "batch.ppm"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout
+    batch = read_ppm(os.path.join(str(tmp_path), "batch.ppm"))
+    for passes in (1, 7):
+        r = subprocess.run([viewer, scene, "--assets", ASSETS, "--passes", str(passes), "--dump", f"v{passes}"],
+                           cwd=str(tmp_path), capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stdout
+        assert "Rendering took" in r.stdout and "kilopixels per second" in r.stdout
+        assert np.array_equal(read_ppm(os.path.join(str(tmp_path), "ray.ppm")), batch)
+        filled = [int((read_ppm(os.path.join(str(tmp_path), f"v{passes}-{i:03d}.ppm")).sum(axis=2) > 0).sum())
+                  for i in range(passes)]
+        assert all(b > a for a, b in zip(filled, filled[1:])) and filled[-1] > 0.9 * batch.shape[0] * batch.shape[1]
