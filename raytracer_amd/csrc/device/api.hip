@@ -13,6 +13,7 @@
 #include "scene_dev.h"
 #include "kernels.h"
 #include "bvh_build.h"
+#include "bvh_device.h"
 
 extern "C" void rtamd_set_error(const char *fmt, ...);
 
@@ -303,6 +304,21 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	std::vector<DevBvhNode> nodes;
 	std::vector<DevTriangle> tris, normals;
 	std::vector<DevTriEdges> edges;
+	// Which meshes get their BVH built on the GPU: RTAMD_BVH=device all of them,
+	// RTAMD_BVH=host none; by default those with at least 2^18 triangles, where the
+	// host's SAH build (about a microsecond per triangle and level) starts to cost
+	// more than the frames it speeds up.
+	const char *bvh_mode = getenv("RTAMD_BVH");
+	auto device_build = [&](int ntri) {
+		if (bvh_mode && !strcmp(bvh_mode, "device")) return true;
+		if (bvh_mode && !strcmp(bvh_mode, "host")) return false;
+		return ntri >= (1 << 18);
+	};
+	struct PendingBuild {
+		int mesh;
+		std::vector<float> pos, nrm;
+	};
+	std::vector<PendingBuild> pending;
 	for (int m = 0; m < h.num_meshes; m++) {
 		const rtamd_mesh &bmh = bmesh[m];
 		const double *v = reinterpret_cast<const double *>(base + bmh.off_vertex);
@@ -334,6 +350,28 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 			for (int c = 0; c < 3; c++)
 				for (int a = 0; a < 3; a++)
 					pos[9 * (size_t)i + 3 * c + a] = (float)v[3 * (size_t)t[6 * i + c] + a];
+		DevMesh &dm = meshes[m];
+		dm.node_first = (int32_t)nodes.size();
+		dm.tri_first = (int32_t)tris.size();
+		dm.num_triangles = nt;
+		if (device_build(nt)) {
+			// built on the GPU once the arrays are uploaded: reserve the mesh's part
+			PendingBuild pb;
+			pb.mesh = m;
+			pb.pos.swap(pos);
+			pb.nrm.resize(9 * (size_t)nt);
+			for (int i = 0; i < nt; i++)
+				for (int c = 0; c < 3; c++)
+					for (int a = 0; a < 3; a++)
+						pb.nrm[9 * (size_t)i + 3 * c + a] = (float)n[3 * (size_t)t[6 * i + 3 + c] + a];
+			pending.push_back(std::move(pb));
+			nodes.resize(nodes.size() + (size_t)(nt > 1 ? nt - 1 : 1));
+			tris.resize(tris.size() + (size_t)nt);
+			normals.resize(normals.size() + (size_t)nt);
+			edges.resize(edges.size() + (size_t)nt);
+			sc->mesh_build_seconds.push_back(0.0);
+			continue;
+		}
 		BvhResult bvh;
 		const auto build_t0 = std::chrono::steady_clock::now();
 		const bool built = bvh_build_mesh(pos.data(), nt, bvh);
@@ -343,11 +381,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 			rtamd_set_error("mesh %d: could not build a BVH within the traversal stack depth", m);
 			return RTAMD_ERR_LIMIT;
 		}
-		DevMesh &dm = meshes[m];
-		dm.node_first = (int32_t)nodes.size();
-		dm.tri_first = (int32_t)tris.size();
 		dm.root = bvh.root;
-		dm.num_triangles = nt;
 		nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
 		for (int i = 0; i < nt; i++) {
 			int orig = bvh.order[i];
@@ -400,6 +434,31 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	if ((rc = upload(sc, normals, &d.normals))) return rc;
 	if ((rc = upload(sc, edges, &d.edges))) return rc;
 	if ((rc = upload(sc, texels, &d.texels))) return rc;
+
+	for (const PendingBuild &pb : pending) {
+		const auto build_t0 = std::chrono::steady_clock::now();
+		const float *d_pos = nullptr, *d_nrm = nullptr;
+		if ((rc = upload(sc, pb.pos, &d_pos))) return rc;
+		if ((rc = upload(sc, pb.nrm, &d_nrm))) return rc;
+		DevMesh &dm = meshes[pb.mesh];
+		int root = 0, depth = 0;
+		HIP_TRY(bvh_build_device(d_pos, d_nrm, dm.num_triangles, const_cast<DevBvhNode *>(d.nodes) + dm.node_first,
+				const_cast<DevTriangle *>(d.tris) + dm.tri_first, const_cast<DevTriangle *>(d.normals) + dm.tri_first,
+				const_cast<DevTriEdges *>(d.edges) + dm.tri_first, &root, &depth, nullptr));
+		if (depth > RT_MAX_STACK - 2) {
+			rtamd_set_error("mesh %d: the BVH built on the device is %d levels deep, more than the traversal "
+					"stack holds (%d); set RTAMD_BVH=host", pb.mesh, depth, RT_MAX_STACK - 2);
+			return RTAMD_ERR_LIMIT;
+		}
+		dm.root = root;
+		sc->mesh_build_seconds[pb.mesh] =
+				std::chrono::duration<double>(std::chrono::steady_clock::now() - build_t0).count();
+	}
+	if (!pending.empty()) {
+		// the mesh table again, now with the roots of the device-built trees
+		HIP_TRY(hipMemcpy(const_cast<DevMesh *>(d.meshes), meshes.data(), meshes.size() * sizeof(DevMesh),
+				hipMemcpyHostToDevice));
+	}
 
 	void *p = nullptr;
 	HIP_TRY(hipMalloc(&p, sizeof(DevCounters)));

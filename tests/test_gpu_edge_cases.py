@@ -153,3 +153,53 @@ def test_queue_overflow_is_reported_and_harmless(render, tmp_path, monkeypatch):
     assert e.value.status == -7 and "earlier render" in str(e.value)
     dev.close()
     check(render, blob)
+
+
+@pytest.mark.parametrize("name", ["showcase-uffizi", "3-aa", "8-glossy", "prims"])
+def test_device_built_bvh_gives_the_same_frame_as_the_host_built_one(render, monkeypatch, name):
+    """The BVH built by the GPU kernels (linear BVH) against the host's SAH tree: hit
+    records (surface, triangle, t, position, normal), ray counts and the frame are
+    bitwise equal - the tree's shape is not observable."""
+    from conftest import small_blob
+    blob = small_blob(name)
+    p = render.make_params(rng_mode=_abi.RNG_KEYED)
+    monkeypatch.setenv("RTAMD_BVH", "host")
+    host = render.DeviceScene(blob)
+    monkeypatch.setenv("RTAMD_BVH", "device")
+    dev = render.DeviceScene(blob)
+    monkeypatch.delenv("RTAMD_BVH")
+    fh, hh, sh = host.render(p, want_hits=True)
+    fd, hd, sd = dev.render(p, want_hits=True)
+    assert_hits_equal(hd, hh)
+    assert np.array_equal(fd.cpu().numpy().view(np.uint32), fh.cpu().numpy().view(np.uint32))
+    assert (sd.rays_primary, sd.rays_shadow, sd.rays_secondary) == (sh.rays_primary, sh.rays_shadow, sh.rays_secondary)
+    host.close()
+    dev.close()
+
+
+def test_device_built_bvh_on_degenerate_meshes(render, tmp_path, monkeypatch):
+    """One triangle, two triangles, many coincident centroids (equal Morton codes)."""
+    monkeypatch.setenv("RTAMD_BVH", "device")
+    body = FLOOR + '<Translate vector="-0.5 1 0"><Scale scale="3 3 3"><Shape geometry="tri" material="shiny" /></Scale></Translate>\n'
+    check(render, write_scene(tmp_path, "dev-one-triangle", body))
+    # a fan of 40 triangles that share a centroid up to rounding, plus a far outlier
+    lines = ["vn 0 0 1"]
+    import math
+    for k in range(40):
+        a = 2 * math.pi * k / 40
+        lines += [f"v {math.cos(a):.6f} {math.sin(a):.6f} {0.01 * k:.6f}",
+                  f"v {math.cos(a + 2.0944):.6f} {math.sin(a + 2.0944):.6f} {0.01 * k:.6f}",
+                  f"v {math.cos(a + 4.1888):.6f} {math.sin(a + 4.1888):.6f} {0.01 * k:.6f}"]
+    lines += ["v 30 30 0", "v 31 30 0", "v 30 31 0"]
+    for k in range(41):
+        lines.append(f"f {3 * k + 1}//1 {3 * k + 2}//1 {3 * k + 3}//1")
+    obj = tmp_path / "fan.obj"
+    obj.write_text("\n".join(lines) + "\n")
+    body = FLOOR + ('<Translate vector="0 1.5 0"><Rotate axis="1 0 0" angle="-60">'
+                    '<Shape geometry="fan" material="shiny" /></Rotate></Translate>\n')
+    text = HEAD.format(w=48, h=32, aa_on="true", aa=2, ss=3, assets=ASSETS, cubemap="").replace(
+        "</Geometry>", f'<Mesh src="{obj}" name="fan" />\n</Geometry>') + body + TAIL
+    path = os.path.join(str(tmp_path), "dev-fan.sdl")
+    with open(path, "w") as f:
+        f.write(text)
+    check(render, ra.load_sdl(path))
