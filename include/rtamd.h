@@ -192,7 +192,9 @@ enum rtamd_rng_mode {
 	/* The reference's serial rand() stream indexed in closed form:
 	 * draw 2*((j*W+i)*aa^2+k)+{0,1} feeds AA sample k of pixel (i,j).  Exact
 	 * only for scenes whose consumption is fixed (no area light, no glossy
-	 * material); rejected otherwise. */
+	 * material); rejected otherwise.  The draws are generated on the device by
+	 * jumping into the stream, one group of tile rows at a time: any frame
+	 * size works as long as one row of tiles draws at most 2^28 values. */
 	RTAMD_RNG_GLIBC = 0,
 	/* Counter-based generator keyed on (seed, pixel, sample, path, purpose,
 	 * index): independent of tiling, GPU count and execution order. */
@@ -264,7 +266,8 @@ int rtamd_render(rtamd_scene *scene, const rtamd_render_params *params,
  * process ends; the call makes no hipMalloc / hipFree.  Limits, reported as
  * RTAMD_ERR_LIMIT / RTAMD_ERR_ARG: the accumulators of a reflective frame (24
  * bytes per owned pixel) and at least one workgroup's worth of queued rays must
- * fit into the array; RTAMD_RNG_GLIBC is accepted only without antialiasing.
+ * fit into the array, and so must the rand() draws of one row of tiles in the
+ * RTAMD_RNG_GLIBC mode with antialiasing (8 Mi draws at most).
  * Calls on one GPU share the array: calls that overlap in time (other streams,
  * other scenes) race; serialise them.  A queue overflow is reported by the next
  * render call on the scene or by rtamd_scene_destroy. */

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "bvh_build.h"
 #include "bvh_device.h"
+#include "front.h"
 
 extern "C" void rtamd_set_error(const char *fmt, ...);
 
@@ -36,6 +37,8 @@ int g_device = -1;
 const unsigned QUEUE_CAPACITY_MAX = 1u << 26;   // rays per bounce queue (80 B each)
 const unsigned QUEUE_CAPACITY_MIN = 1u << 16;
 const unsigned RT_SCAN_MAX_SEGMENTS = 4096;     // what k_scan_of_sums handles
+const unsigned long long GLIBC_TABLE_DRAWS_DEFAULT = 1ull << 24;   // serial-stream table: 64 MiB
+const unsigned long long GLIBC_TABLE_DRAWS_MAX = 1ull << 28;
 
 } // namespace
 
@@ -47,9 +50,15 @@ struct rtamd_scene {
 	bool glossy;                 // some material in use spawns reflection_samples children
 	// image-plane extents for the two `near` values the drivers pass
 	// lazily created work buffers
+	// serial-stream mode: a bounded table of draws, refilled per group of tile rows by
+	// k_glibc_fill from the jump polynomials and the seed's first raw values
 	int32_t *d_glibc = nullptr;
-	uint32_t glibc_seed = 0;
-	unsigned long long glibc_n = 0;
+	unsigned long long glibc_capacity = 0;       // draws the table holds
+	unsigned long long glibc_capacity_max = 0;   // RTAMD_GLIBC_TABLE_DRAWS (test knob) or the default
+	uint32_t *d_glibc_powers = nullptr;          // 2048 x 31 words
+	uint32_t *d_glibc_window = nullptr;          // RT_GLIBC_BLOCK + 31 words, for window_seed
+	uint32_t glibc_window_seed = 0;
+	bool glibc_window_valid = false;
 	long long *d_accum = nullptr;
 	unsigned long long accum_slots = 0;
 	QueueItem *d_queue[2] = { nullptr, nullptr };
@@ -159,6 +168,8 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 	for (void *p : sc->allocations)
 		(void)hipFree(p);
 	if (sc->d_glibc) (void)hipFree(sc->d_glibc);
+	if (sc->d_glibc_powers) (void)hipFree(sc->d_glibc_powers);
+	if (sc->d_glibc_window) (void)hipFree(sc->d_glibc_window);
 	if (sc->d_accum) (void)hipFree(sc->d_accum);
 	if (sc->d_queue[0]) (void)hipFree(sc->d_queue[0]);
 	if (sc->d_queue[1]) (void)hipFree(sc->d_queue[1]);
@@ -482,6 +493,11 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		sc->queue_capacity_max = c >= RT_BLOCK && c < QUEUE_CAPACITY_MAX ? (unsigned)c : QUEUE_CAPACITY_MAX;
 		const char *at = getenv("RTAMD_QUEUE_OVERFLOW_AT");
 		sc->overflow_test_capacity = at ? (unsigned)strtoul(at, nullptr, 0) : 0;
+		// RTAMD_GLIBC_TABLE_DRAWS bounds the serial-stream table (frames are then rendered
+		// in more groups of tile rows)
+		const char *draws = getenv("RTAMD_GLIBC_TABLE_DRAWS");
+		const unsigned long long dr = draws ? strtoull(draws, nullptr, 0) : 0;
+		sc->glibc_capacity_max = dr >= 1024 && dr <= GLIBC_TABLE_DRAWS_MAX ? dr : GLIBC_TABLE_DRAWS_DEFAULT;
 	}
 	return 0;
 }
@@ -573,35 +589,104 @@ static int normalise_params(int width, int height, const rtamd_render_params *in
 	return 0;
 }
 
-// The serial rand() stream for closed-form indexing (2 draws per primary sample).
-static int ensure_glibc_table(rtamd_scene *sc, uint32_t seed, hipStream_t stream)
+// ---- the serial rand() stream, generated on the device ---------------------------
+//
+// Draw 2*((j*W+i)*aa^2+k)+{0,1} feeds sample k of pixel (i,j): the draws of a run of
+// pixel rows are one contiguous run of the stream.  A render call walks its tile
+// rows in groups whose draws fit a bounded table; k_glibc_fill produces each group's
+// run by jumping into the stream (polynomial arithmetic, front/glibc_rand.c) right
+// before the primary kernel that reads it, on the same stream.
+
+// The tabulated powers x^(BLOCK * i) and x^(BLOCK * 1024 * i), i < 1024: the same for
+// every seed and scene, computed once per process.
+static const std::vector<uint32_t> &glibc_powers_host()
+{
+	static std::vector<uint32_t> table;
+	if (table.empty()) {
+		std::vector<uint32_t> t((size_t)2048 * RT_GLIBC_POLY);
+		for (int level = 0; level < 2; level++) {
+			uint32_t step[RT_GLIBC_POLY], cur[RT_GLIBC_POLY] = { 1 }, next[RT_GLIBC_POLY];
+			front_glibc_poly_pow(level ? (uint64_t)RT_GLIBC_BLOCK * 1024 : (uint64_t)RT_GLIBC_BLOCK, step);
+			for (int i = 0; i < 1024; i++) {
+				std::memcpy(&t[((size_t)level * 1024 + i) * RT_GLIBC_POLY], cur, sizeof cur);
+				front_glibc_poly_mul(cur, step, next);
+				std::memcpy(cur, next, sizeof cur);
+			}
+		}
+		table.swap(t);
+	}
+	return table;
+}
+
+// Uploads the powers (once) and the seed's window (when the seed changes) into the
+// given device buffers.  No allocation.
+static int glibc_upload_tables(rtamd_scene *sc, uint32_t seed, uint32_t *d_powers, bool powers_valid,
+		uint32_t *d_window, bool window_valid, hipStream_t stream)
+{
+	if (!powers_valid) {
+		const std::vector<uint32_t> &t = glibc_powers_host();
+		HIP_TRY(hipMemcpyAsync(d_powers, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+	}
+	if (!window_valid) {
+		uint32_t w[RT_GLIBC_BLOCK + RT_GLIBC_POLY];
+		front_glibc_window(seed, w, RT_GLIBC_BLOCK + RT_GLIBC_POLY);
+		HIP_TRY(hipMemcpyAsync(d_window, w, sizeof w, hipMemcpyHostToDevice, stream));
+		// the source is on this function's stack: the copy must have left it
+		HIP_TRY(hipStreamSynchronize(stream));
+	}
+	(void)sc;
+	return 0;
+}
+
+// Fills table[0 .. count) with the draws first .. first + count - 1.
+static int glibc_fill(const uint32_t *d_powers, const uint32_t *d_window, int32_t *table,
+		unsigned long long first, unsigned long long count, hipStream_t stream)
+{
+	GlibcJump start;
+	front_glibc_poly_pow(RT_GLIBC_FIRST_DRAW + first, start.c);
+	HIP_TRY(rt_launch_glibc_fill(start, d_powers, d_window, table, count, stream));
+	return 0;
+}
+
+// rtamd_render / rtamd_camera_rays: the scene's own buffers, allocated on first use;
+// the table holds at least `want` draws afterwards (or the configured maximum).
+static int ensure_glibc_buffers(rtamd_scene *sc, uint32_t seed, unsigned long long want,
+		unsigned long long at_least, hipStream_t stream)
 {
 	if (!sc->dev.antialiasing)
 		return 0;
-	unsigned long long n = 2ull * (unsigned long long)sc->dev.width * (unsigned long long)sc->dev.height *
-			(unsigned long long)sc->dev.spp;
-	if (n > (1ull << 31)) {
-		rtamd_set_error("the rand() stream table for this frame needs %llu entries; the limit is 2^31 "
-				"(use RTAMD_RNG_KEYED)", n);
-		return RTAMD_ERR_LIMIT;
+	const bool had_powers = sc->d_glibc_powers != nullptr;
+	void *p = nullptr;
+	if (!sc->d_glibc_powers) {
+		HIP_TRY(hipMalloc(&p, (size_t)2048 * RT_GLIBC_POLY * sizeof(uint32_t)));
+		sc->d_glibc_powers = static_cast<uint32_t *>(p);
+		HIP_TRY(hipMalloc(&p, (RT_GLIBC_BLOCK + RT_GLIBC_POLY) * sizeof(uint32_t)));
+		sc->d_glibc_window = static_cast<uint32_t *>(p);
 	}
-	if (sc->d_glibc && sc->glibc_seed == seed && sc->glibc_n == n)
-		return 0;
-	if (sc->d_glibc) {
-		HIP_TRY(hipStreamSynchronize(stream));
-		(void)hipFree(sc->d_glibc);
-		sc->d_glibc = nullptr;
-	}
-	std::vector<int32_t> table(n);
-	int rc = rtamd_glibc_rand_fill(seed, 0, n, table.data());
+	const bool window_ok = sc->glibc_window_valid && sc->glibc_window_seed == seed;
+	if (!window_ok)
+		HIP_TRY(hipStreamSynchronize(stream));     // an earlier fill may still read the old window
+	int rc = glibc_upload_tables(sc, seed, sc->d_glibc_powers, had_powers, sc->d_glibc_window, window_ok, stream);
 	if (rc)
 		return rc;
-	void *p = nullptr;
-	HIP_TRY(hipMalloc(&p, n * sizeof(int32_t)));
-	sc->d_glibc = static_cast<int32_t *>(p);
-	HIP_TRY(hipMemcpy(p, table.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
-	sc->glibc_seed = seed;
-	sc->glibc_n = n;
+	sc->glibc_window_seed = seed;
+	sc->glibc_window_valid = true;
+	// the configured size, but never less than one row of tiles needs (if that is allowed at all)
+	if (want > sc->glibc_capacity_max)
+		want = sc->glibc_capacity_max;
+	if (want < at_least && at_least <= GLIBC_TABLE_DRAWS_MAX)
+		want = at_least;
+	if (sc->glibc_capacity < want) {
+		if (sc->d_glibc) {
+			HIP_TRY(hipStreamSynchronize(stream));
+			(void)hipFree(sc->d_glibc);
+			sc->d_glibc = nullptr;
+			sc->glibc_capacity = 0;
+		}
+		HIP_TRY(hipMalloc(&p, want * sizeof(int32_t)));
+		sc->d_glibc = static_cast<int32_t *>(p);
+		sc->glibc_capacity = want;
+	}
 	return 0;
 }
 
@@ -615,7 +700,10 @@ struct RenderWork {
 	unsigned *qcount;            // 128 counters, one per bounce level
 	DevCounters *counters;
 	BounceWork bounce;           // hits == null: unsorted bounce pass
-	const int32_t *glibc;
+	// serial-stream mode with antialiasing: the draw table and what fills it
+	int32_t *glibc;
+	unsigned long long glibc_capacity;
+	const uint32_t *glibc_powers, *glibc_window;
 };
 
 // Owns the HIP events of one call so that every return path releases them.
@@ -687,6 +775,28 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 	if (chunk > max_chunk)
 		chunk = max_chunk - max_chunk % RT_BLOCK;
 
+	// Serial-stream mode with antialiasing: the tile rows are walked in groups whose
+	// draws fit the table; otherwise there is one group, all rows.
+	int row0 = 0, row1 = 0;
+	rt_window_tile_rows(dev.width, dev.height, p, &row0, &row1);
+	const bool streamed = p.rng_mode == RTAMD_RNG_GLIBC && dev.antialiasing;
+	int rows_per_group = row1 - row0;
+	const unsigned long long draws_per_pixel_row = 2ull * (unsigned)dev.width * (unsigned)dev.spp;
+	if (streamed) {
+		const unsigned long long per_tile_row = draws_per_pixel_row * (unsigned)p.tile_h;
+		if (!w.glibc || w.glibc_capacity < per_tile_row) {
+			rtamd_set_error("the rand() stream table holds %llu draws; one row of %d-pixel-high tiles of this "
+					"frame needs %llu (use smaller tiles, or RTAMD_RNG_KEYED)", w.glibc_capacity, p.tile_h,
+					per_tile_row);
+			return RTAMD_ERR_LIMIT;
+		}
+		const unsigned long long fit = w.glibc_capacity / per_tile_row;
+		if (fit < (unsigned long long)rows_per_group)
+			rows_per_group = (int)fit;
+	}
+	if (rows_per_group < 1)
+		rows_per_group = 1;
+
 	unsigned kernel_capacity = w.queue_capacity;
 	if (sc->overflow_test_capacity && sc->overflow_test_capacity < kernel_capacity)
 		kernel_capacity = sc->overflow_test_capacity;
@@ -708,38 +818,57 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 		unsigned long long blocks = ((unsigned long long)w.queue_capacity + RT_BLOCK - 1) / RT_BLOCK;
 		bounce_grid = blocks > 2048 ? 2048u : (unsigned)blocks;
 	}
-	for (unsigned long long first = sample_lo; first < samples; first += chunk) {
-		unsigned long long count = samples - first < chunk ? samples - first : chunk;
-		if (levels)
-			HIP_TRY(hipMemsetAsync(w.qcount, 0, sizeof(unsigned) * 128, stream));
-		const bool timed = stats && ev.chunks.size() < 2 * MAX_TIMED_CHUNKS;
-		if (timed) {
-			hipEvent_t e = nullptr;
-			HIP_TRY(hipEventCreate(&e));
-			ev.chunks.push_back(e);
-			HIP_TRY(hipEventRecord(e, stream));
+	for (int g0 = row0; g0 < row1; g0 += rows_per_group) {
+		const int g1 = g0 + rows_per_group < row1 ? g0 + rows_per_group : row1;
+		unsigned long long tile_lo = 0, tile_hi = 0;
+		rt_tile_rows_range(dev.width, dev.height, p, g0, g1, &tile_lo, &tile_hi);
+		const unsigned long long per_tile = (unsigned long long)p.tile_w * (unsigned)p.tile_h * (unsigned)dev.spp;
+		const unsigned long long group_lo = tile_lo * per_tile, group_hi = tile_hi * per_tile;
+		GlibcTable table = { w.glibc, 0 };
+		if (streamed && group_hi > group_lo) {
+			const unsigned long long y0 = (unsigned long long)g0 * (unsigned)p.tile_h;
+			unsigned long long y1 = (unsigned long long)g1 * (unsigned)p.tile_h;
+			if (y1 > (unsigned)dev.height)
+				y1 = (unsigned)dev.height;
+			table.first = y0 * draws_per_pixel_row;
+			int rc = glibc_fill(w.glibc_powers, w.glibc_window, w.glibc, table.first, (y1 - y0) * draws_per_pixel_row,
+					stream);
+			if (rc)
+				return rc;
 		}
-		HIP_TRY(rt_launch_primary(dev, p, first, count, w.glibc, accum,
-				direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits),
-				levels ? w.queue[0] : nullptr, levels ? w.qcount : nullptr, kernel_capacity, w.counters, stream));
-		if (timed) {
-			hipEvent_t e = nullptr;
-			HIP_TRY(hipEventCreate(&e));
-			ev.chunks.push_back(e);
-			HIP_TRY(hipEventRecord(e, stream));
-		}
-		launches_primary++;
-		for (int level = 1; level <= levels; level++) {
-			// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
-			if (w.bounce.hits)
-				HIP_TRY(rt_launch_bounce_sorted(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
-						kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
-						w.qcount + level, w.counters, w.bounce, bounce_grid, stream));
-			else
-				HIP_TRY(rt_launch_bounce(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
-						kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
-						w.qcount + level, w.counters, bounce_grid, stream));
-			launches_bounce++;
+		for (unsigned long long first = group_lo; first < group_hi; first += chunk) {
+			unsigned long long count = group_hi - first < chunk ? group_hi - first : chunk;
+			if (levels)
+				HIP_TRY(hipMemsetAsync(w.qcount, 0, sizeof(unsigned) * 128, stream));
+			const bool timed = stats && ev.chunks.size() < 2 * MAX_TIMED_CHUNKS;
+			if (timed) {
+				hipEvent_t e = nullptr;
+				HIP_TRY(hipEventCreate(&e));
+				ev.chunks.push_back(e);
+				HIP_TRY(hipEventRecord(e, stream));
+			}
+			HIP_TRY(rt_launch_primary(dev, p, first, count, table, accum,
+					direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits),
+					levels ? w.queue[0] : nullptr, levels ? w.qcount : nullptr, kernel_capacity, w.counters, stream));
+			if (timed) {
+				hipEvent_t e = nullptr;
+				HIP_TRY(hipEventCreate(&e));
+				ev.chunks.push_back(e);
+				HIP_TRY(hipEventRecord(e, stream));
+			}
+			launches_primary++;
+			for (int level = 1; level <= levels; level++) {
+				// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
+				if (w.bounce.hits)
+					HIP_TRY(rt_launch_bounce_sorted(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
+							kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
+							w.qcount + level, w.counters, w.bounce, bounce_grid, stream));
+				else
+					HIP_TRY(rt_launch_bounce(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
+							kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
+							w.qcount + level, w.counters, bounce_grid, stream));
+				launches_bounce++;
+			}
 		}
 	}
 	HIP_TRY(rt_launch_collect_stats(w.counters, stream));
@@ -824,7 +953,9 @@ static int render_prepare(rtamd_scene *sc, const rtamd_render_params *params, vo
 		return RTAMD_ERR_LIMIT;
 	}
 	unsigned long long tile_lo, tile_hi;
-	rt_window_tile_range(sc->dev.width, sc->dev.height, *p, &tile_lo, &tile_hi);
+	int row0 = 0, row1 = 0;
+	rt_window_tile_rows(sc->dev.width, sc->dev.height, *p, &row0, &row1);
+	rt_tile_rows_range(sc->dev.width, sc->dev.height, *p, row0, row1, &tile_lo, &tile_hi);
 	const unsigned long long per_tile = (unsigned long long)p->tile_w * (unsigned)p->tile_h;
 	*pix_lo = tile_lo * per_tile;
 	*pix_hi = tile_hi * per_tile;
@@ -845,9 +976,16 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 	if (rc)
 		return rc;
 	const unsigned long long pixels = pix_hi - pix_lo;
-	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
-		return rc;
 	const DevScene &dev = sc->dev;
+	if (p.rng_mode == RTAMD_RNG_GLIBC) {
+		// the draws of the tile rows this call renders, capped at the table's maximum
+		int r0 = 0, r1 = 0;
+		rt_window_tile_rows(dev.width, dev.height, p, &r0, &r1);
+		const unsigned long long rows = (unsigned long long)(r1 - r0) * (unsigned)p.tile_h;
+		const unsigned long long per_row = 2ull * (unsigned)dev.width * (unsigned)dev.spp;
+		if ((rc = ensure_glibc_buffers(sc, p.seed, per_row * rows, per_row * (unsigned)p.tile_h, stream)))
+			return rc;
+	}
 	const unsigned long long samples = pixels * (unsigned)dev.spp;
 	// work buffers
 	if (!direct && sc->accum_slots < pixels) {
@@ -907,6 +1045,9 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 	if (!sc->sorted_bounce)
 		w.bounce.hits = nullptr;
 	w.glibc = sc->d_glibc;
+	w.glibc_capacity = sc->glibc_capacity;
+	w.glibc_powers = sc->d_glibc_powers;
+	w.glibc_window = sc->d_glibc_window;
 	return render_impl(sc, p, w, direct, pix_lo, pix_hi, d_colour, d_hits, stats, stream);
 }
 
@@ -922,6 +1063,13 @@ static __device__ __align__(256) unsigned char scratch[RTAMD_NOALLOC_SCRATCH_BYT
 namespace {
 const int MAX_DEVICES = 64;
 unsigned char *g_scratch_ptr[MAX_DEVICES];
+// where in a device's scratch the serial-stream tables of the last call lie, and for which seed
+struct ScratchStream {
+	uint32_t *powers = nullptr;
+	uint32_t window_seed = 0;
+	bool window_valid = false;
+};
+ScratchStream g_scratch_stream[MAX_DEVICES];
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }
@@ -953,11 +1101,6 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	if (rc)
 		return rc;
 	const unsigned long long pixels = pix_hi - pix_lo;
-	if (p.rng_mode == RTAMD_RNG_GLIBC && sc->dev.antialiasing) {
-		rtamd_set_error("rtamd_render_noalloc: RTAMD_RNG_GLIBC with antialiasing needs a table of the rand() "
-				"stream, which this entry point does not allocate; use RTAMD_RNG_KEYED or rtamd_render");
-		return RTAMD_ERR_ARG;
-	}
 	unsigned char *base = (sc->device >= 0 && sc->device < MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;
 	if (!base) {
 		rtamd_set_error("rtamd_render_noalloc: no scratch address for device %d (rtamd_init not called?)",
@@ -980,6 +1123,39 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	if (sorted) {
 		w.bounce.hist = reinterpret_cast<unsigned *>(base + off);
 		off = align_up(off + n_bins * sizeof(unsigned), 256);
+	}
+	const bool streamed = p.rng_mode == RTAMD_RNG_GLIBC && sc->dev.antialiasing;
+	if (streamed) {
+		// jump polynomials and the seed's window keep their place from call to call (they
+		// are uploaded again only when the seed changes); the table takes at most 32 MiB
+		ScratchStream &st = g_scratch_stream[sc->device];
+		uint32_t *powers = reinterpret_cast<uint32_t *>(base + off);
+		off = align_up(off + (size_t)2048 * RT_GLIBC_POLY * sizeof(uint32_t), 256);
+		uint32_t *window = reinterpret_cast<uint32_t *>(base + off);
+		off = align_up(off + (RT_GLIBC_BLOCK + RT_GLIBC_POLY) * sizeof(uint32_t), 256);
+		const bool same_place = st.powers == powers;
+		const bool window_ok = same_place && st.window_valid && st.window_seed == p.seed;
+		if (!window_ok)
+			HIP_TRY(hipStreamSynchronize(stream));
+		if ((rc = glibc_upload_tables(sc, p.seed, powers, same_place, window, window_ok, stream)))
+			return rc;
+		st.powers = powers;
+		st.window_seed = p.seed;
+		st.window_valid = true;
+		int r0 = 0, r1 = 0;
+		rt_window_tile_rows(sc->dev.width, sc->dev.height, p, &r0, &r1);
+		unsigned long long draws = 2ull * (unsigned)sc->dev.width * (unsigned)sc->dev.spp *
+				((unsigned long long)(r1 - r0) * (unsigned)p.tile_h);
+		if (draws > (8ull << 20))
+			draws = 8ull << 20;
+		w.glibc = reinterpret_cast<int32_t *>(base + off);
+		w.glibc_capacity = draws;
+		w.glibc_powers = powers;
+		w.glibc_window = window;
+		off = align_up(off + (size_t)draws * sizeof(int32_t), 256);
+	} else {
+		// another layout follows: the stream tables lose their place
+		g_scratch_stream[sc->device].powers = nullptr;
 	}
 	if (!direct) {
 		const size_t bytes = (size_t)pixels * 3 * sizeof(long long);
@@ -1020,7 +1196,6 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		rtamd_set_error("rtamd_render_noalloc: internal layout error (%zu bytes)", off);
 		return RTAMD_ERR_LIMIT;
 	}
-	w.glibc = nullptr;
 	return render_impl(sc, p, w, direct, pix_lo, pix_hi, d_colour, nullptr, nullptr, stream);
 }
 
@@ -1054,13 +1229,28 @@ extern "C" int rtamd_camera_rays(rtamd_scene *sc, const rtamd_render_params *par
 		return rc;
 	if ((rc = use_scene_device(sc)))
 		return rc;
-	if (p.rng_mode == RTAMD_RNG_GLIBC && (rc = ensure_glibc_table(sc, p.seed, stream)))
-		return rc;
+	GlibcTable table = { nullptr, 0 };
+	if (p.rng_mode == RTAMD_RNG_GLIBC && sc->dev.antialiasing) {
+		// every sample of the frame is written by one launch: the whole frame's draws
+		const unsigned long long draws = 2ull * (unsigned)sc->dev.width * (unsigned)sc->dev.height * (unsigned)sc->dev.spp;
+		const unsigned long long keep = sc->glibc_capacity_max;
+		if (draws > GLIBC_TABLE_DRAWS_MAX) {
+			rtamd_set_error("rtamd_camera_rays: the frame draws %llu values of the rand() stream; this entry "
+					"point handles %llu (render windows of it, or use RTAMD_RNG_KEYED)", draws, GLIBC_TABLE_DRAWS_MAX);
+			return RTAMD_ERR_LIMIT;
+		}
+		sc->glibc_capacity_max = draws > keep ? draws : keep;
+		rc = ensure_glibc_buffers(sc, p.seed, draws, draws, stream);
+		sc->glibc_capacity_max = keep;
+		if (rc || (rc = glibc_fill(sc->d_glibc_powers, sc->d_glibc_window, sc->d_glibc, 0, draws, stream)))
+			return rc;
+		table.draws = sc->d_glibc;
+	}
 	if (rt_owned_pixels(sc->dev.width, sc->dev.height, p) * (unsigned)sc->dev.spp > 0x7fffffffull * 256) {
 		rtamd_set_error("rtamd_camera_rays: too many samples in one call");
 		return RTAMD_ERR_LIMIT;
 	}
-	HIP_TRY(rt_launch_camera_rays(sc->dev, p, sc->d_glibc, static_cast<double *>(d_rays), stream));
+	HIP_TRY(rt_launch_camera_rays(sc->dev, p, table, static_cast<double *>(d_rays), stream));
 	return 0;
 }
 

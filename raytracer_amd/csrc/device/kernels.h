@@ -7,11 +7,14 @@
 
 int rt_tiles_owned(int width, int height, const rtamd_render_params &p);
 unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_params &p);
-void rt_window_tile_range(int width, int height, const rtamd_render_params &p, unsigned long long *lo,
-		unsigned long long *hi);
+void rt_tile_rows_range(int width, int height, const rtamd_render_params &p, int row0, int row1,
+		unsigned long long *lo, unsigned long long *hi);
+void rt_window_tile_rows(int width, int height, const rtamd_render_params &p, int *row0, int *row1);
+hipError_t rt_launch_glibc_fill(const GlibcJump &start, const uint32_t *powers, const uint32_t *window,
+		int32_t *out, unsigned long long count, hipStream_t stream);
 
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
-		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
+		unsigned long long sample_first, unsigned long long sample_count, GlibcTable glibc_table,
 		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
 		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
 hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
@@ -39,7 +42,7 @@ hipError_t rt_launch_collect_stats(DevCounters *counters, hipStream_t stream);
 hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
 		rtamd_hit_record *hits, hipStream_t stream);
 hipError_t rt_launch_camera_rays(const DevScene &sc, const rtamd_render_params &p,
-		const int32_t *glibc_table, double *rays, hipStream_t stream);
+		GlibcTable glibc_table, double *rays, hipStream_t stream);
 hipError_t rt_launch_tiles_copy(int width, int height, const rtamd_render_params &p, float *frame,
 		float *packed, int unpack, hipStream_t stream);
 

@@ -59,7 +59,7 @@ namespace {
 
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES)
 k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
-		int rng_mode, uint32_t seed, const int32_t *glibc_table, long long *accum, float *direct_out,
+		int rng_mode, uint32_t seed, GlibcTable glibc_table, long long *accum, float *direct_out,
 		rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count, unsigned queue_capacity,
 		DevCounters *counters)
 {
@@ -657,6 +657,76 @@ __global__ void k_collect_stats(DevCounters *counters)
 }
 #endif
 
+// The reference's rand() stream (ray.c:14-17 after srand, raytracer.c:74) for a run
+// of draws, generated where it is used.  The generator is linear: its raw values
+// obey w[i+31] = w[i+28] + w[i] (mod 2^32), so with c(x) = x^n mod (x^31 - x^28 - 1)
+// the value at n + k is sum_j c[j] w[j + k] over the first values of the sequence.
+// A workgroup produces RT_GLIBC_BLOCK consecutive draws: it multiplies the launch's
+// starting polynomial by the tabulated powers x^(RT_GLIBC_BLOCK * b) for its own
+// block number b (two polynomial products), then every thread combines the window
+// w[0 .. RT_GLIBC_BLOCK + 30] with the 31 coefficients.  draw = value >> 1.
+DEV void glibc_poly_mul_block(uint32_t *a, const uint32_t *b, uint32_t *e)
+{
+	// a = a * b mod p; a in LDS, b anywhere, e = 61 words of LDS
+	const int k = threadIdx.x;
+	if (k < 2 * RT_GLIBC_POLY - 1) {
+		uint32_t v = 0;
+		const int i0 = k > RT_GLIBC_POLY - 1 ? k - (RT_GLIBC_POLY - 1) : 0;
+		const int i1 = k < RT_GLIBC_POLY - 1 ? k : RT_GLIBC_POLY - 1;
+		for (int i = i0; i <= i1; i++)
+			v += a[i] * b[k - i];
+		e[k] = v;
+	}
+	__syncthreads();
+	if (k == 0)
+		for (int m = 2 * RT_GLIBC_POLY - 2; m >= RT_GLIBC_POLY; m--) {
+			e[m - 3] += e[m];
+			e[m - RT_GLIBC_POLY] += e[m];
+		}
+	__syncthreads();
+	if (k < RT_GLIBC_POLY)
+		a[k] = e[k];
+	__syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+k_glibc_fill(GlibcJump start, const uint32_t *powers, const uint32_t *window, int32_t *out, unsigned long long count)
+{
+	__shared__ uint32_t s_c[RT_GLIBC_POLY], s_e[2 * RT_GLIBC_POLY - 1];
+	__shared__ uint32_t s_w[RT_GLIBC_BLOCK + RT_GLIBC_POLY];
+	for (int i = threadIdx.x; i < RT_GLIBC_BLOCK + RT_GLIBC_POLY; i += 256)
+		s_w[i] = window[i];
+	if (threadIdx.x < RT_GLIBC_POLY)
+		s_c[threadIdx.x] = start.c[threadIdx.x];
+	__syncthreads();
+	const unsigned b = blockIdx.x;
+	// powers[0 .. 1024) = x^(BLOCK * i), powers[1024 .. 2048) = x^(BLOCK * 1024 * i)
+	glibc_poly_mul_block(s_c, powers + (size_t)(1024 + (b >> 10)) * RT_GLIBC_POLY, s_e);
+	glibc_poly_mul_block(s_c, powers + (size_t)(b & 1023) * RT_GLIBC_POLY, s_e);
+	uint32_t c[RT_GLIBC_POLY];
+	for (int j = 0; j < RT_GLIBC_POLY; j++)
+		c[j] = s_c[j];
+	const unsigned long long base = (unsigned long long)b * RT_GLIBC_BLOCK;
+	for (int k = threadIdx.x; k < RT_GLIBC_BLOCK; k += 256) {
+		if (base + (unsigned)k >= count)
+			break;
+		uint32_t v = 0;
+		for (int j = 0; j < RT_GLIBC_POLY; j++)
+			v += c[j] * s_w[j + k];
+		out[base + (unsigned)k] = (int32_t)(v >> 1);
+	}
+}
+
+hipError_t rt_launch_glibc_fill(const GlibcJump &start, const uint32_t *powers, const uint32_t *window,
+		int32_t *out, unsigned long long count, hipStream_t stream)
+{
+	if (!count)
+		return hipSuccess;
+	const unsigned long long blocks = (count + RT_GLIBC_BLOCK - 1) / RT_GLIBC_BLOCK;
+	hipLaunchKernelGGL(k_glibc_fill, dim3((unsigned)blocks), dim3(256), 0, stream, start, powers, window, out, count);
+	return hipGetLastError();
+}
+
 // Accumulators -> the reference's float RGBA frame (raytracer.c:46,81): the
 // per-pixel sum is scaled by the float 1.0/aa^2 when antialiasing is on.
 __global__ void k_resolve(DevScene sc, TileMap tm, unsigned long long pixel_first, unsigned long long pixel_count,
@@ -723,7 +793,7 @@ k_trace(DevScene sc, const double *rays, unsigned long long n, rtamd_hit_record 
 
 // camera_ray / camera_ray_aa for every sample of the selection (ray.h:23-24).
 __global__ void k_camera_rays(DevScene sc, TileMap tm, unsigned long long sample_count, int rng_mode,
-		uint32_t seed, const int32_t *glibc_table, double *rays)
+		uint32_t seed, GlibcTable glibc_table, double *rays)
 {
 	unsigned long long sample = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (sample >= sample_count)
@@ -797,15 +867,14 @@ unsigned long long rt_owned_pixels(int width, int height, const rtamd_render_par
 	return (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h);
 }
 
-// The owned tiles that a call's pixel window can touch: positions [lo, hi) in the
-// owner's tile sequence (tiles are numbered row by row, so the tile rows a window
-// spans are one contiguous run of tile numbers).  The whole frame: [0, owned).
-void rt_window_tile_range(int width, int height, const rtamd_render_params &p, unsigned long long *lo,
-		unsigned long long *hi)
+// Positions [lo, hi) in the owner's tile sequence of the owned tiles that lie in the
+// tile rows [row0, row1) (tiles are numbered row by row, so a run of tile rows is one
+// contiguous run of tile numbers).
+void rt_tile_rows_range(int width, int height, const rtamd_render_params &p, int row0, int row1,
+		unsigned long long *lo, unsigned long long *hi)
 {
 	const TileMap tm = make_tile_map(width, height, p);
-	const long long t0 = (long long)(tm.y0 / tm.tile_h) * tm.tiles_x;
-	const long long t1 = (long long)((tm.y1 - 1) / tm.tile_h + 1) * tm.tiles_x;
+	const long long t0 = (long long)row0 * tm.tiles_x, t1 = (long long)row1 * tm.tiles_x;
 	auto position = [&](long long tile) {
 		// number of owned tiles below `tile`: ceil((tile - first) / stride), within [0, owned]
 		long long n = tile <= tm.tile_first ? 0 : (tile - tm.tile_first + tm.tile_stride - 1) / tm.tile_stride;
@@ -815,8 +884,16 @@ void rt_window_tile_range(int width, int height, const rtamd_render_params &p, u
 	*hi = position(t1);
 }
 
+// The tile rows [row0, row1) that a call's pixel window touches (the whole frame: all rows).
+void rt_window_tile_rows(int width, int height, const rtamd_render_params &p, int *row0, int *row1)
+{
+	const TileMap tm = make_tile_map(width, height, p);
+	*row0 = tm.y0 / tm.tile_h;
+	*row1 = (tm.y1 - 1) / tm.tile_h + 1;
+}
+
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
-		unsigned long long sample_first, unsigned long long sample_count, const int32_t *glibc_table,
+		unsigned long long sample_first, unsigned long long sample_count, GlibcTable glibc_table,
 		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
 		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream)
 {
@@ -900,7 +977,7 @@ hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long
 }
 
 hipError_t rt_launch_camera_rays(const DevScene &sc, const rtamd_render_params &p,
-		const int32_t *glibc_table, double *rays, hipStream_t stream)
+		GlibcTable glibc_table, double *rays, hipStream_t stream)
 {
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long samples = (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h) * (unsigned)sc.spp;

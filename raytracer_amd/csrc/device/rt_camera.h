@@ -45,7 +45,7 @@ DEV Ray camera_ray(const DevScene &sc, int i, int j, float offx, float offy)
 	return r;
 }
 
-DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_table, uint32_t seed,
+DEV void sample_offsets(const DevScene &sc, int rng_mode, const GlibcTable glibc_table, uint32_t seed,
 		int px, int py, int k, uint32_t &key, float &offx, float &offy)
 {
 	uint32_t pixel = (uint32_t)(sc.width * py + px);
@@ -60,10 +60,11 @@ DEV void sample_offsets(const DevScene &sc, int rng_mode, const int32_t *glibc_t
 	int p = k % aa, q = k / aa;
 	double r0, r1;
 	if (rng_mode == RTAMD_RNG_GLIBC) {
-		// draw 2*((j*W+i)*aa^2+k)+{0,1} of the serial stream
-		unsigned long long idx = 2ull * ((unsigned long long)pixel * (unsigned)sc.spp + (unsigned)k);
-		r0 = (double)glibc_table[idx] / ((double)2147483647);
-		r1 = (double)glibc_table[idx + 1] / ((double)2147483647);
+		// draw 2*((j*W+i)*aa^2+k)+{0,1} of the serial stream; the table holds the draws
+		// from glibc_table.first on
+		unsigned long long idx = 2ull * ((unsigned long long)pixel * (unsigned)sc.spp + (unsigned)k) - glibc_table.first;
+		r0 = (double)glibc_table.draws[idx] / ((double)2147483647);
+		r1 = (double)glibc_table.draws[idx + 1] / ((double)2147483647);
 	} else {
 		r0 = keyed_drand(key, PURPOSE_AA, 0);
 		r1 = keyed_drand(key, PURPOSE_AA, 1);

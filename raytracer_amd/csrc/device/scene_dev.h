@@ -150,6 +150,22 @@ struct BounceBin {
 #define RT_SORT_BITS_MAX 8      /* bits per axis of the hit-point grid: at most 2^24 cells */
 #define RT_SCAN_SEGMENT 8192    /* histogram entries scanned by one workgroup */
 
+/* A run of the reference's rand() stream in device memory: draws[i] is draw
+ * number first + i. */
+struct GlibcTable {
+	const int32_t *draws;
+	unsigned long long first;
+};
+
+#define RT_GLIBC_POLY 31        /* degree of the generator's recurrence */
+#define RT_GLIBC_BLOCK 4096     /* draws produced by one workgroup of the fill kernel */
+#define RT_GLIBC_FIRST_DRAW 341 /* raw-sequence position of draw 0 */
+
+/* x^n mod (x^31 - x^28 - 1) with coefficients mod 2^32: where a fill starts */
+struct GlibcJump {
+	uint32_t c[RT_GLIBC_POLY];
+};
+
 struct DevCounters {
 	unsigned long long rays_primary, rays_shadow, rays_secondary, env_lookups;
 	unsigned long long queue_overflow;

@@ -34,6 +34,20 @@ int front_png_load(const char *path, int *width, int *height, int *channels,
 /* zlib-wrapped DEFLATE stream -> exactly out_len bytes. */
 int front_inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
 
+/* ---- jump-ahead in the rand() stream (glibc_rand.c) ----
+ * The generator's raw values w[i] obey w[i+31] = w[i+28] + w[i] (mod 2^32), so for
+ * c(x) = x^n mod (x^31 - x^28 - 1), with coefficients mod 2^32,
+ *     w[n + k] = sum_j c[j] * w[j + k]      for every k >= 0,
+ * and draw d of the stream is w[GLIBC_FIRST_DRAW + d] >> 1. */
+#define GLIBC_POLY 31
+#define GLIBC_FIRST_DRAW 341
+/* c = x^n mod p */
+void front_glibc_poly_pow(uint64_t n, uint32_t c[GLIBC_POLY]);
+/* out = a * b mod p (out may alias neither) */
+void front_glibc_poly_mul(const uint32_t a[GLIBC_POLY], const uint32_t b[GLIBC_POLY], uint32_t out[GLIBC_POLY]);
+/* w[0 .. count) for a seed */
+void front_glibc_window(uint32_t seed, uint32_t *w, int count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,3 +402,16 @@ def test_showcase_scene_fields_by_hand():
     lo, hi = obj_vertex_bounds("tablecloth.obj")
     assert list(s[3].bbox) == [float(x) for x in lo] + [float(x) for x in hi]
     assert all((m.reflect, m.glossiness) == (0.0, 0.0) for m in b.materials)
+
+
+def test_rand_stream_jump_ahead_equals_walking_it():
+    """rtamd_glibc_rand_fill far into the stream jumps there with polynomial arithmetic
+    (the generator is linear); the result must be what walking the stream gives."""
+    seed = 0x20071208
+    walked = ra.glibc_rand(seed, 0, 3_000_000)
+    for first in (4095, 4096, 4097, 65536, 1_000_003, 2_999_000):
+        assert np.array_equal(ra.glibc_rand(seed, first, 1000), walked[first:first + 1000]), first
+    # two jumps that meet: the last values of one run are the first of the next
+    a = ra.glibc_rand(7, 5_000_000_000, 100)
+    b = ra.glibc_rand(7, 5_000_000_050, 50)
+    assert np.array_equal(a[50:], b)
