@@ -61,12 +61,12 @@ struct rtamd_scene {
 	bool glibc_window_valid = false;
 	long long *d_accum = nullptr;
 	unsigned long long accum_slots = 0;
-	QueueItem *d_queue[2] = { nullptr, nullptr };
+	QueueItem *d_queue[3] = { nullptr, nullptr, nullptr };   // level 1; deeper levels alternate between the other two
 	unsigned queue_capacity = 0;
 	unsigned *d_qcount = nullptr;
 	DevCounters *d_counters = nullptr;
 	// coherent bounce pass (see kernels.hip): per-entry scratch sized like the queues
-	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0 };
+	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1 };
 	unsigned bounce_capacity = 0;
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	int device = -1;             // the device the scene's buffers live on
@@ -155,7 +155,7 @@ static void free_bounce_work(rtamd_scene *sc)
 	for (void *p : ptrs)
 		if (p)
 			(void)hipFree(p);
-	w = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.bits };
+	w = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.bits, w.small_below, w.hits_per_wave };
 	sc->bounce_capacity = 0;
 }
 
@@ -171,8 +171,9 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 	if (sc->d_glibc_powers) (void)hipFree(sc->d_glibc_powers);
 	if (sc->d_glibc_window) (void)hipFree(sc->d_glibc_window);
 	if (sc->d_accum) (void)hipFree(sc->d_accum);
-	if (sc->d_queue[0]) (void)hipFree(sc->d_queue[0]);
-	if (sc->d_queue[1]) (void)hipFree(sc->d_queue[1]);
+	for (QueueItem *q : sc->d_queue)
+		if (q)
+			(void)hipFree(q);
 	if (sc->d_qcount) (void)hipFree(sc->d_qcount);
 	if (sc->d_counters) (void)hipFree(sc->d_counters);
 	free_bounce_work(sc);
@@ -304,6 +305,14 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		const char *bits = getenv("RTAMD_SORT_BITS");
 		int b = bits ? atoi(bits) : 7;
 		sc->bounce.bits = b < 1 ? 1 : (b > RT_SORT_BITS_MAX ? RT_SORT_BITS_MAX : b);
+		// Levels of fewer hits than this (RTAMD_SMALL_LEVEL, 0 = never) are shaded with each
+		// hit's light samples across the lanes of a wave: as many hits to a wave as have
+		// their n x n samples side by side in 64 lanes.
+		const char *small = getenv("RTAMD_SMALL_LEVEL");
+		sc->bounce.small_below = small ? (unsigned)strtoul(small, nullptr, 0) : 262144u;
+		const int m = h.shadow_samples * h.shadow_samples;
+		int per_wave = m >= 64 ? 1 : 64 / m;
+		sc->bounce.hits_per_wave = (unsigned)(per_wave > 8 ? 8 : per_wave);
 	}
 	sc->fixed_consumption = !any_area && !any_glossy;
 	sc->glossy = any_glossy;
@@ -695,7 +704,7 @@ static int ensure_glibc_buffers(rtamd_scene *sc, uint32_t seed, unsigned long lo
 // rtamd_render_noalloc carves them out of this device's static scratch array.
 struct RenderWork {
 	long long *accum;            // 3 x int64 per owned pixel, or null (direct frames)
-	QueueItem *queue[2];
+	QueueItem *queue[3];         // [0]: rays of depth 1; [1], [2]: deeper levels, alternating
 	unsigned queue_capacity;
 	unsigned *qcount;            // 128 counters, one per bounce level
 	DevCounters *counters;
@@ -721,15 +730,21 @@ struct EventSet {
 };
 const size_t MAX_TIMED_CHUNKS = 2048;
 
-// worst-case children per primary sample at any level (shading.c:88: only depths 0
-// and 1 fan out)
-static unsigned long long queue_fan(const rtamd_scene *sc)
+// Children one path vertex can spawn: reflection_samples at depths 0 and 1 of a
+// glossy material, one otherwise (shading.c:88).
+static unsigned long long vertex_fan(const rtamd_scene *sc)
 {
 	const DevScene &dev = sc->dev;
 	if (!(dev.any_reflective && sc->glossy))
 		return 1;
-	const unsigned long long rs = (unsigned)(dev.reflection_samples > 1 ? dev.reflection_samples : 1);
-	return dev.max_reflections >= 2 ? rs * rs : rs;
+	return (unsigned)(dev.reflection_samples > 1 ? dev.reflection_samples : 1);
+}
+
+// Whether rays of depth 1 can fan out again: then their queue is worked off in
+// slices whose children fit the next queue.
+static bool second_fan(const rtamd_scene *sc)
+{
+	return sc->dev.any_reflective && sc->glossy && sc->dev.max_reflections >= 2;
 }
 
 // A queue overflow of an earlier asynchronous call: the resolve step of that call
@@ -757,7 +772,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 	const unsigned long long pixels = pix_hi - pix_lo;
 	const unsigned long long sample_lo = pix_lo * (unsigned)dev.spp, samples = pix_hi * (unsigned)dev.spp;
 	long long *const accum = w.accum ? w.accum - 3 * (long long)pix_lo : nullptr;
-	const unsigned long long fan = queue_fan(sc);
+	const unsigned long long fan = vertex_fan(sc);
 	unsigned long long chunk = samples - sample_lo;
 	if (!chunk)
 		chunk = RT_BLOCK;
@@ -857,17 +872,30 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 				HIP_TRY(hipEventRecord(e, stream));
 			}
 			launches_primary++;
-			for (int level = 1; level <= levels; level++) {
-				// queue (level-1)&1 holds the rays of depth `level`; their children go to level&1
-				if (w.bounce.hits)
-					HIP_TRY(rt_launch_bounce_sorted(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
-							kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
-							w.qcount + level, w.counters, w.bounce, bounce_grid, stream));
-				else
-					HIP_TRY(rt_launch_bounce(dev, w.queue[(level - 1) & 1], w.qcount + (level - 1),
-							kernel_capacity, accum, level < levels ? w.queue[level & 1] : nullptr,
-							w.qcount + level, w.counters, bounce_grid, stream));
-				launches_bounce++;
+			// Rays of depth 1 wait in queue 0.  Where they can fan out again they are taken
+			// in slices of capacity / fan entries, so that a slice's children fit a queue;
+			// every slice is followed down to the last level before the next one starts
+			// (slices beyond the population find nothing and cost a few empty launches).
+			const unsigned slices = second_fan(sc) ? (unsigned)fan : 1u;
+			const unsigned slice_len = w.queue_capacity / slices;
+			for (unsigned sl = 0; sl < slices; sl++) {
+				if (sl > 0 || levels > 1)
+					HIP_TRY(hipMemsetAsync(w.qcount + 1, 0, sizeof(unsigned) * 127, stream));
+				for (int level = 1; level <= levels; level++) {
+					QueueSlice in;
+					in.items = level == 1 ? w.queue[0] : w.queue[1 + (level & 1)];
+					in.count = w.qcount + (level - 1);
+					in.capacity = kernel_capacity;
+					in.first = level == 1 ? sl * slice_len : 0;
+					in.limit = level == 1 ? slice_len : kernel_capacity;
+					QueueItem *out = level < levels ? w.queue[1 + ((level + 1) & 1)] : nullptr;
+					if (w.bounce.hits)
+						HIP_TRY(rt_launch_bounce_sorted(dev, in, accum, out, w.qcount + level, w.counters, w.bounce,
+								bounce_grid, stream));
+					else
+						HIP_TRY(rt_launch_bounce(dev, in, accum, out, w.qcount + level, w.counters, bounce_grid, stream));
+					launches_bounce++;
+				}
 			}
 		}
 	}
@@ -1001,18 +1029,18 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		sc->accum_slots = pixels;
 	}
 	if (dev.any_reflective) {
-		unsigned long long want = samples * queue_fan(sc);
+		unsigned long long want = samples * vertex_fan(sc);
 		unsigned cap = want > sc->queue_capacity_max ? sc->queue_capacity_max
 				: (want < QUEUE_CAPACITY_MIN ? QUEUE_CAPACITY_MIN : (unsigned)want);
 		if (sc->queue_capacity < cap) {
 			HIP_TRY(hipStreamSynchronize(stream));
-			for (int q = 0; q < 2; q++) {
+			for (int q = 0; q < 3; q++) {
 				if (sc->d_queue[q])
 					(void)hipFree(sc->d_queue[q]);
 				sc->d_queue[q] = nullptr;
 			}
 			sc->queue_capacity = 0;
-			for (int q = 0; q < 2; q++) {
+			for (int q = 0; q < 3; q++) {
 				void *ptr = nullptr;
 				HIP_TRY(hipMalloc(&ptr, (size_t)cap * sizeof(QueueItem)));
 				sc->d_queue[q] = static_cast<QueueItem *>(ptr);
@@ -1038,6 +1066,7 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 	w.accum = direct ? nullptr : sc->d_accum;
 	w.queue[0] = sc->d_queue[0];
 	w.queue[1] = sc->d_queue[1];
+	w.queue[2] = sc->d_queue[2];
 	w.queue_capacity = sc->queue_capacity;
 	w.qcount = sc->d_qcount;
 	w.counters = sc->d_counters;
@@ -1120,6 +1149,8 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	w.bounce.bounds = reinterpret_cast<unsigned *>(base + off); off = align_up(off + 8 * sizeof(unsigned), 256);
 	w.bounce.sums = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + RT_SCAN_MAX_SEGMENTS * sizeof(unsigned), 256);
 	w.bounce.bits = bits;
+	w.bounce.small_below = sc->bounce.small_below;
+	w.bounce.hits_per_wave = sc->bounce.hits_per_wave;
 	if (sorted) {
 		w.bounce.hist = reinterpret_cast<unsigned *>(base + off);
 		off = align_up(off + n_bins * sizeof(unsigned), 256);
@@ -1169,23 +1200,24 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		off = align_up(off + bytes, 256);
 	}
 	if (sc->dev.any_reflective) {
-		const size_t per_entry = 2 * sizeof(QueueItem) + (sorted ? sizeof(BounceHit) + sizeof(BounceBin) + sizeof(unsigned) : 0);
-		size_t cap = (RTAMD_NOALLOC_SCRATCH_BYTES - off - 5 * 256) / per_entry;
+		const size_t per_entry = 3 * sizeof(QueueItem) + (sorted ? sizeof(BounceHit) + sizeof(BounceBin) + sizeof(unsigned) : 0);
+		size_t cap = (RTAMD_NOALLOC_SCRATCH_BYTES - off - 6 * 256) / per_entry;
 		cap -= cap % 256;
-		const unsigned long long want = pixels * (unsigned)sc->dev.spp * queue_fan(sc);
+		const unsigned long long want = pixels * (unsigned)sc->dev.spp * vertex_fan(sc);
 		if (cap > want)
 			cap = (size_t)align_up((size_t)want, 256);
 		if (cap > sc->queue_capacity_max)
 			cap = sc->queue_capacity_max;
-		if (cap < queue_fan(sc) * RT_BLOCK) {
+		if (cap < vertex_fan(sc) * vertex_fan(sc) * RT_BLOCK) {
 			rtamd_set_error("rtamd_render_noalloc: the scratch array leaves room for %zu queued rays, fewer "
 					"than one workgroup of samples can spawn (%llu); use rtamd_render", cap,
-					queue_fan(sc) * RT_BLOCK);
+					vertex_fan(sc) * vertex_fan(sc) * RT_BLOCK);
 			return RTAMD_ERR_LIMIT;
 		}
 		w.queue_capacity = (unsigned)cap;
 		w.queue[0] = reinterpret_cast<QueueItem *>(base + off);  off = align_up(off + cap * sizeof(QueueItem), 256);
 		w.queue[1] = reinterpret_cast<QueueItem *>(base + off);  off = align_up(off + cap * sizeof(QueueItem), 256);
+		w.queue[2] = reinterpret_cast<QueueItem *>(base + off);  off = align_up(off + cap * sizeof(QueueItem), 256);
 		if (sorted) {
 			w.bounce.hits = reinterpret_cast<BounceHit *>(base + off);  off = align_up(off + cap * sizeof(BounceHit), 256);
 			w.bounce.bins = reinterpret_cast<BounceBin *>(base + off);  off = align_up(off + cap * sizeof(BounceBin), 256);

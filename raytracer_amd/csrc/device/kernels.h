@@ -17,9 +17,6 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, GlibcTable glibc_table,
 		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
 		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
-hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
-		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
-		DevCounters *counters, unsigned grid_blocks, hipStream_t stream);
 /* Scratch of one bounce level of the coherent pass: per queue entry the nearest
  * hit, its bin and the sorted order; the bin histogram ((2^bits)^3 + 1 entries,
  * scanned in place), the per-segment sums of the scan, the hit-point bounds. */
@@ -31,10 +28,14 @@ struct BounceWork {
 	unsigned *sums;
 	unsigned *bounds;
 	int bits;
+	unsigned small_below;    /* levels of fewer hits are shaded with their samples across lanes; 0 = never */
+	unsigned hits_per_wave;  /* ... this many hits to a wave */
 };
-hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
-		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
-		DevCounters *counters, const BounceWork &work, unsigned grid_blocks, hipStream_t stream);
+hipError_t rt_launch_bounce(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
+		unsigned *queue_out_count, DevCounters *counters, unsigned grid_blocks, hipStream_t stream);
+hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
+		unsigned *queue_out_count, DevCounters *counters, const BounceWork &work, unsigned grid_blocks,
+		hipStream_t stream);
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
 		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
 		unsigned long long *overflow_out, hipStream_t stream);

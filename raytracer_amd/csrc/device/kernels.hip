@@ -38,6 +38,16 @@ namespace {
 // Kernels
 // =============================================================================
 
+// entries of the slice that exist
+DEV unsigned slice_count(const QueueSlice &q)
+{
+	unsigned total = *q.count;
+	if (total > q.capacity)
+		total = q.capacity;
+	unsigned n = total > q.first ? total - q.first : 0;
+	return n < q.limit ? n : q.limit;
+}
+
 // Primary samples: camera ray, nearest hit, direct lighting with shadow rays,
 // environment lookup; children go to the bounce queue.  raytracer.c:32-54,78-84.
 // Register budget: the primary kernel is fastest at five waves per SIMD (<= 96
@@ -212,9 +222,10 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 // weight, is added to its pixel.  Grid-stride over the queue population, which
 // is read from device memory so the host never waits between bounces.
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
-k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count, unsigned queue_capacity,
+k_bounce(DevScene sc, QueueSlice in, unsigned queue_capacity,
 		long long *accum, QueueItem *queue_out, unsigned *queue_out_count, DevCounters *counters)
 {
+	const QueueItem *queue_in = in.items + in.first;
 #if RT_BOUNCE_PACKET
 	// consecutive queue entries come from the lanes of one spawning wave (one
 	// pixel's samples): they are coherent enough to walk the BVH as a packet
@@ -232,11 +243,9 @@ k_bounce(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count,
 		s_timing[threadIdx.x >> 6][threadIdx.x & 63] = 0;
 #endif
 	TM_BEGIN(t_kernel);
-	unsigned count = *queue_in_count;
-	if (count > queue_capacity)
-		count = queue_capacity;
+	const unsigned count = slice_count(in);
 	if (blockIdx.x == 0 && threadIdx.x == 0)
-		atomicMax(&counters->queue_peak, (unsigned long long)count);
+		atomicMax(&counters->queue_peak, (unsigned long long)*in.count);
 	const unsigned stride = gridDim.x * RT_BLOCK;
 	// every lane of a wave runs the same number of iterations (the wave-level
 	// compaction inside shade_vertex needs all 64 lanes present)
@@ -323,21 +332,20 @@ DEV float ordered_to_float(unsigned e)
 // bounds[0..2] = min x y z (ordered encoding, atomicMin), bounds[3..5] = ~max
 // (atomicMin as well, so that one 0xff fill initialises all six).
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
-k_bounce_trace(DevScene sc, const QueueItem *queue_in, const unsigned *queue_in_count, unsigned queue_capacity,
-		long long *accum, BounceHit *bhit, unsigned *bounds, DevCounters *counters)
+k_bounce_trace(DevScene sc, QueueSlice in, long long *accum, BounceHit *bhit, unsigned *bounds,
+		DevCounters *counters)
 {
 	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
 	int *stack = s_stack + threadIdx.x;
-	unsigned count = *queue_in_count;
-	if (count > queue_capacity)
-		count = queue_capacity;
+	const QueueItem *queue_in = in.items + in.first;
+	const unsigned count = slice_count(in);
 	if (blockIdx.x == 0 && threadIdx.x == 0)
-		atomicMax(&counters->queue_peak, (unsigned long long)count);
-	const unsigned stride = gridDim.x * RT_BLOCK;
-	const unsigned rounds = (count + stride - 1) / stride;
+		atomicMax(&counters->queue_peak, (unsigned long long)*in.count);
 	unsigned n_env = 0, n_rays = 0;
 	const float inf = __builtin_huge_valf();
 	float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+	const unsigned stride = gridDim.x * RT_BLOCK;
+	const unsigned rounds = (count + stride - 1) / stride;
 	for (unsigned round = 0; round < rounds; round++) {
 		const unsigned idx = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
 		if (idx >= count)
@@ -401,12 +409,11 @@ DEV unsigned spread3(unsigned v)
 
 // Bin of every hit: Morton code of its cell in a (2^bits)^3 grid over the bounds
 // of this level's hit points; misses and unused slots go to the extra last bin.
-__global__ void k_bounce_bin(const QueueItem *queue_in, const unsigned *queue_in_count, unsigned queue_capacity,
-		const BounceHit *bhit, const unsigned *bounds, unsigned *hist, BounceBin *bbin, int bits)
+__global__ void k_bounce_bin(QueueSlice in, const BounceHit *bhit, const unsigned *bounds, unsigned *hist,
+		BounceBin *bbin, int bits)
 {
-	unsigned count = *queue_in_count;
-	if (count > queue_capacity)
-		count = queue_capacity;
+	const QueueItem *queue_in = in.items + in.first;
+	const unsigned count = slice_count(in);
 	const unsigned cells = 1u << bits;
 	float lo[3], scale[3];
 	for (int a = 0; a < 3; a++) {
@@ -542,12 +549,9 @@ k_scan_segments(unsigned *hist, unsigned n, const unsigned *sums)
 	}
 }
 
-__global__ void k_bounce_scatter(const unsigned *queue_in_count, unsigned queue_capacity, const BounceBin *bbin,
-		const unsigned *offsets, unsigned *perm)
+__global__ void k_bounce_scatter(QueueSlice in, const BounceBin *bbin, const unsigned *offsets, unsigned *perm)
 {
-	unsigned count = *queue_in_count;
-	if (count > queue_capacity)
-		count = queue_capacity;
+	const unsigned count = slice_count(in);
 	const unsigned stride = gridDim.x * blockDim.x;
 	for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += stride) {
 		const BounceBin b = bbin[idx];
@@ -561,11 +565,14 @@ __global__ void k_bounce_scatter(const unsigned *queue_in_count, unsigned queue_
 // hit points next to a mesh holds too many leaves, and a packet of their rays is
 // the union of 64 pyramids), 451 ms with the transposed loops on sorted hits, and
 // 552 ms for the unsorted pass.
+// It takes a level only when the level holds at least `min_hits` hits; smaller
+// levels go to k_bounce_shade_small.
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
-k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, const BounceHit *bhit,
-		const unsigned *perm, unsigned queue_capacity, long long *accum, QueueItem *queue_out,
-		unsigned *queue_out_count, DevCounters *counters)
+k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, unsigned min_hits,
+		const BounceHit *bhit, const unsigned *perm, unsigned queue_capacity, long long *accum, QueueItem *queue_out,
+		unsigned *queue_out_count, DevCounters *counters, unsigned *cursor)
 {
+	__shared__ unsigned s_base;
 	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
 	int *stack = s_stack + threadIdx.x;
 #ifdef RT_TIMING
@@ -576,14 +583,25 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, c
 	unsigned count = *n_hits;
 	if (count > queue_capacity)
 		count = queue_capacity;
-	const unsigned stride = gridDim.x * RT_BLOCK;
-	// every lane of a wave runs the same number of iterations (the wave-level
-	// compaction of the children needs all 64 lanes present)
-	const unsigned rounds = (count + stride - 1) / stride;
+	if (count < min_hits)
+		return;
 	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, nullptr, nullptr, nullptr };
 	unsigned n_shadow = 0;
-	for (unsigned round = 0; round < rounds; round++) {
-		const unsigned i = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
+	// Hit points differ widely in what their shadow rays cost (open floor against the
+	// inside of a mesh): workgroups fetch batches of RT_BLOCK hits from a shared cursor
+	// instead of owning a fixed share (measured: 310 -> 287 ms on 8-glossy; batches of 64
+	// per wave 305 ms, the four waves of a workgroup then work in different places).
+	// The cursor starts at 0xffffffff (the fill that initialises the bounds), so the
+	// first batch is old + 1 = 0.
+	for (;;) {
+		__syncthreads();
+		if (threadIdx.x == 0)
+			s_base = atomicAdd(cursor, (unsigned)RT_BLOCK) + 1u;
+		__syncthreads();
+		const unsigned base = s_base;
+		if (base >= count)
+			break;
+		const unsigned i = base + threadIdx.x;
 		const bool active = i < count;
 		unsigned idx = 0;
 		d3 ray_d = { 0, 0, 1 };
@@ -626,6 +644,76 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, c
 	if ((threadIdx.x & 63) < TM_COUNT)
 		atomicAdd(&g_timing_bounce[threadIdx.x & 63], s_timing[threadIdx.x >> 6][threadIdx.x & 63]);
 #endif
+}
+
+// The same step for a level of fewer than `max_hits` hits.  One lane per hit would
+// leave most of the GPU idle while a few waves walk 2 n^2 shadow rays per lane one
+// after the other (a level of any size then takes as long as a lane takes).  Here
+// a wave takes only as many hits as have their light samples side by side in its
+// 64 lanes (lights_transposed: lane = (hit, sample), one packet walk per light),
+// so a small level spreads over many waves and finishes in the time of a few
+// packet walks.  Same sums per hit, in the same order.
+__global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
+k_bounce_shade_small(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, unsigned max_hits,
+		unsigned hits_per_wave, const BounceHit *bhit, const unsigned *perm, unsigned queue_capacity, long long *accum,
+		QueueItem *queue_out, unsigned *queue_out_count, DevCounters *counters)
+{
+	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
+	__shared__ int4 s_wave_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
+	__shared__ float s_wave_sum[RT_BLOCK / 64][384];
+	int *stack = s_stack + threadIdx.x;
+	unsigned count = *n_hits;
+	if (count > queue_capacity)
+		count = queue_capacity;
+	if (count >= max_hits)
+		return;
+	const unsigned wave_in_block = threadIdx.x >> 6, lane = lane_id();
+	const unsigned waves = gridDim.x * (RT_BLOCK / 64);
+	const unsigned groups = (count + hits_per_wave - 1) / hits_per_wave;
+	const unsigned rounds = (groups + waves - 1) / waves;
+	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, nullptr,
+		reinterpret_cast<int *>(s_wave_stack + wave_in_block * RT_MAX_STACK), s_wave_sum[wave_in_block] };
+	unsigned n_shadow = 0;
+	for (unsigned round = 0; round < rounds; round++) {
+		const unsigned group = round * waves + blockIdx.x * (RT_BLOCK / 64) + wave_in_block;
+		const unsigned i = group * hits_per_wave + lane;
+		const bool active = lane < hits_per_wave && group < groups && i < count;
+		unsigned idx = 0;
+		d3 ray_d = { 0, 0, 1 };
+		c3 weight = { 0, 0, 0 };
+		uint32_t slot = 0, key = 0, depth = 0;
+		int surface = 0;
+		d3 position = { 0, 0, 0 }, normal = { 0, 0, 0 };
+		if (active) {
+			idx = perm[i];
+			const QueueItem it = queue_in[idx];
+			const BounceHit h = bhit[idx];
+			Ray ray;
+			ray.o = { it.o[0], it.o[1], it.o[2] };
+			ray.d = { it.d[0], it.d[1], it.d[2] };
+			ray.tnear = 0;
+			ray.tfar = __builtin_huge_valf();
+			ray_d = ray.d;
+			weight = { it.weight[0], it.weight[1], it.weight[2] };
+			slot = it.slot; key = it.key; depth = it.depth;
+			Best best;
+			best.surface = h.surface; best.tri = h.tri; best.ncode = h.ncode; best.t = h.t;
+			best.a = h.a; best.b = h.b; best.c = h.c;
+			surface = h.surface;
+			finish_hit(sc, ray, best, position, normal);
+		}
+		auto ray_again = [&]() {
+			unsigned q = idx;
+			asm volatile("" : "+v"(q));
+			const double *dq = queue_in[q].d;
+			return d3{ dq[0], dq[1], dq[2] };
+		};
+		const c3 total = shade_hit<false, true>(io, active, surface, position, normal, ray_d, depth, key, weight, slot,
+				stack, n_shadow, ray_again);
+		if (active)
+			accumulate(accum, slot, cmul(weight, total));
+	}
+	wave_count_add(&counters->rays_shadow, n_shadow);
 }
 
 #if defined(RT_TRAVERSAL_STATS) || defined(RT_TIMING)
@@ -907,37 +995,46 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 	return hipGetLastError();
 }
 
-hipError_t rt_launch_bounce(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
-		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
-		DevCounters *counters, unsigned grid_blocks, hipStream_t stream)
+hipError_t rt_launch_bounce(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
+		unsigned *queue_out_count, DevCounters *counters, unsigned grid_blocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_bounce, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, queue_in, queue_in_count,
-			queue_capacity, accum, queue_out, queue_out_count, counters);
+	hipLaunchKernelGGL(k_bounce, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, in, in.capacity, accum, queue_out,
+			queue_out_count, counters);
 	return hipGetLastError();
 }
 
 // One bounce level of the coherent pass.  `work` holds the level's scratch buffers.
-hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueItem *queue_in, const unsigned *queue_in_count,
-		unsigned queue_capacity, long long *accum, QueueItem *queue_out, unsigned *queue_out_count,
-		DevCounters *counters, const BounceWork &work, unsigned grid_blocks, hipStream_t stream)
+hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
+		unsigned *queue_out_count, DevCounters *counters, const BounceWork &work, unsigned grid_blocks,
+		hipStream_t stream)
 {
 	const unsigned n_bins = (1u << (3 * work.bits)) + 1u;
 	const unsigned n_seg = (n_bins + RT_SCAN_SEGMENT - 1) / RT_SCAN_SEGMENT;
 	hipError_t e;
 	if ((e = hipMemsetAsync(work.hist, 0, (size_t)n_bins * sizeof(unsigned), stream)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(work.bounds, 0xff, 8 * sizeof(unsigned), stream)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_bounce_trace, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, queue_in, queue_in_count,
-			queue_capacity, accum, work.hits, work.bounds, counters);
-	hipLaunchKernelGGL(k_bounce_bin, dim3(grid_blocks), dim3(256), 0, stream, queue_in, queue_in_count, queue_capacity,
-			work.hits, work.bounds, work.hist, work.bins, work.bits);
+	hipLaunchKernelGGL(k_bounce_trace, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, in, accum, work.hits,
+			work.bounds, counters);
+	hipLaunchKernelGGL(k_bounce_bin, dim3(grid_blocks), dim3(256), 0, stream, in, work.hits, work.bounds, work.hist,
+			work.bins, work.bits);
 	hipLaunchKernelGGL(k_scan_sums, dim3(n_seg), dim3(256), 0, stream, work.hist, n_bins, work.sums);
 	hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, stream, work.sums, n_seg);
 	hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(256), 0, stream, work.hist, n_bins, work.sums);
-	hipLaunchKernelGGL(k_bounce_scatter, dim3(grid_blocks), dim3(256), 0, stream, queue_in_count, queue_capacity,
-			work.bins, work.hist, work.perm);
-	hipLaunchKernelGGL(k_bounce_shade, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, queue_in,
-			work.hist + (n_bins - 1), work.hits, work.perm, queue_capacity, accum, queue_out, queue_out_count,
-			counters);
+	hipLaunchKernelGGL(k_bounce_scatter, dim3(grid_blocks), dim3(256), 0, stream, in, work.bins, work.hist, work.perm);
+	// levels of fewer hits than the GPU has lanes to give them are shaded by the kernel
+	// that spreads each hit's light samples over a wave
+	const unsigned small_below = work.small_below;
+	const unsigned *n_hits = work.hist + (n_bins - 1);
+	const QueueItem *items = in.items + in.first;
+	hipLaunchKernelGGL(k_bounce_shade, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits, small_below,
+			work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters, work.bounds + 6);
+	if (small_below) {
+		const unsigned per_wave = work.hits_per_wave;
+		unsigned blocks = (small_below / per_wave + RT_BLOCK / 64 - 1) / (RT_BLOCK / 64);
+		if (blocks < 1) blocks = 1;
+		hipLaunchKernelGGL(k_bounce_shade_small, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
+				small_below, per_wave, work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters);
+	}
 	return hipGetLastError();
 }
 

@@ -130,6 +130,15 @@ struct QueueItem {
 	uint32_t pad[2];
 };
 
+/* The part of a bounce queue one launch takes: entries [first, first + limit) of the
+ * queue's population (read on the device, so the host never waits for it). */
+struct QueueSlice {
+	const QueueItem *items;
+	const unsigned *count;      /* the queue's population */
+	unsigned capacity;          /* entries the queue holds; a larger population was cut off */
+	unsigned first, limit;
+};
+
 /* Nearest hit of a queued ray, kept between the trace and the shade kernel of a
  * bounce pass (the position and normal are rebuilt from it, ray.c:574-576). */
 struct BounceHit {
