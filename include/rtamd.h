@@ -162,6 +162,10 @@ int rtamd_blob_validate(const void *blob, size_t blob_size);
 /* Replaces `bool ppm_write(Colour*,int,int,FILE*)` (ppm.h:8, ppm.c:8-35):
  * P6, top row first, byte = (unsigned char)CLAMP(c*255,0,255). */
 int rtamd_ppm_write(const float *colour_rgba, int width, int height, const char *path);
+/* The same image as an 8-bit RGB PNG.  The reference writes PPM only; its vendored
+ * pnglite carries a writer that is never called (pnglite.c:822-846).  Same
+ * quantiser, so the PNG's pixels are the PPM's. */
+int rtamd_png_write(const float *colour_rgba, int width, int height, const char *path);
 /* Same quantiser into memory: rgb8 has 3*width*height bytes, top row first. */
 int rtamd_quantise_rgb8(const float *colour_rgba, int width, int height, uint8_t *rgb8);
 

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "rtamd_blob_free": (None, [C.c_void_p]),
     "rtamd_blob_validate": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rtamd_ppm_write": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "rtamd_png_write": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "rtamd_quantise_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "rtamd_glibc_rand_fill": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
     "rtamd_init": (C.c_int, [C.c_int]),

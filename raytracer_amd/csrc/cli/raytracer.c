@@ -4,7 +4,7 @@
  *   raytracer scene.sdl                       (the reference's one-argument form)
  *   raytracer scene.sdl [--width W] [--height H] [--aa N | --no-aa] [--seed S]
  *             [--rng glibc|keyed] [--device D | --devices D0,D1,...] [--bands N]
- *             [--assets DIR] [-o out.ppm] [--stats]
+ *             [--assets DIR] [-o out.ppm | -o out.png] [--stats]
  *
  * Console contract of the reference, line for line: "Loading cubemap took ..."
  * when the scene has one (scene.c:570-573), per mesh "Building kd-tree for
@@ -224,7 +224,10 @@ int main(int argc, char **argv)
 	if (want_stats)
 		printf("%llu rays, %.3f ms on the device%s, %.1f Mrays/s\n", rays, device_ms, ndev > 1 ? "s" : "",
 				rays / (device_ms * 1e-3) / 1e6);
-	if (rtamd_ppm_write(colour, w, hh, out))
+	/* ray.ppm as the reference writes it; a name ending in .png selects the PNG writer */
+	const size_t len = strlen(out);
+	const int png = len > 4 && !strcmp(out + len - 4, ".png");
+	if (png ? rtamd_png_write(colour, w, hh, out) : rtamd_ppm_write(colour, w, hh, out))
 		return fail(rtamd_last_error());
 	free(colour);
 	for (int k = 0; k < ndev; k++) {

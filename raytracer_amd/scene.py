@@ -159,3 +159,11 @@ def ppm_write(colour, path):
     h, w, _ = colour.shape
     _abi.check(_abi.lib().rtamd_ppm_write(colour.ctypes.data, w, h, os.fsencode(path)),
                "rtamd_ppm_write")
+
+
+def png_write(colour, path):
+    """rtamd_png_write: float [h, w, 4] bottom-up frame -> 8-bit RGB PNG."""
+    colour = np.ascontiguousarray(colour, np.float32)
+    h, w, _ = colour.shape
+    _abi.check(_abi.lib().rtamd_png_write(colour.ctypes.data, w, h, os.fsencode(path)),
+               "rtamd_png_write")

@@ -415,3 +415,29 @@ def test_rand_stream_jump_ahead_equals_walking_it():
     a = ra.glibc_rand(7, 5_000_000_000, 100)
     b = ra.glibc_rand(7, 5_000_000_050, 50)
     assert np.array_equal(a[50:], b)
+
+
+def test_png_writer_round_trips_through_an_independent_decoder(tmp_path):
+    """rtamd_png_write (stored deflate blocks, filter 0) taken apart chunk by chunk and
+    inflated with zlib: the pixels are the PPM quantiser's, every CRC holds."""
+    rng = np.random.default_rng(5)
+    for w, h in ((1, 1), (7, 3), (300, 250)):          # the last one needs more than one stored block
+        colour = rng.uniform(-0.2, 1.2, (h, w, 4)).astype(np.float32)
+        path = str(tmp_path / f"x{w}.png")
+        ra.png_write(colour, path)
+        data = open(path, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(data):
+            n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body)
+            if kind == b"IHDR":
+                ihdr = struct.unpack(">IIBBBBB", body)
+            if kind == b"IDAT":
+                idat += body
+            pos += 12 + n
+        assert ihdr == (w, h, 8, 2, 0, 0, 0)
+        raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+        assert not raw[:, 0].any()
+        assert np.array_equal(raw[:, 1:].reshape(h, w, 3), ra.quantise_rgb8(colour))
