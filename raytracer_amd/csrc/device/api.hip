@@ -481,7 +481,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	}
 
 	void *p = nullptr;
-	HIP_TRY(hipMalloc(&p, sizeof(DevCounters)));
+	HIP_TRY(hipMalloc(&p, sizeof(DevCounters) * RT_COUNTER_COPIES));
 	sc->d_counters = static_cast<DevCounters *>(p);
 	HIP_TRY(hipMalloc(&p, sizeof(unsigned) * 128));
 	sc->d_qcount = static_cast<unsigned *>(p);
@@ -824,7 +824,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 	}
 	if (!direct)
 		HIP_TRY(hipMemsetAsync(w.accum, 0, pixels * 3 * sizeof(long long), stream));
-	HIP_TRY(hipMemsetAsync(w.counters, 0, sizeof(DevCounters), stream));
+	HIP_TRY(hipMemsetAsync(w.counters, 0, sizeof(DevCounters) * RT_COUNTER_COPIES, stream));
 
 	int launches_primary = 0, launches_bounce = 0;
 	const int levels = dev.any_reflective ? dev.max_reflections : 0;
@@ -1144,7 +1144,7 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	size_t off = 0;
 	RenderWork w;
 	std::memset(&w, 0, sizeof w);
-	w.counters = reinterpret_cast<DevCounters *>(base + off);  off = align_up(off + sizeof(DevCounters), 256);
+	w.counters = reinterpret_cast<DevCounters *>(base + off);  off = align_up(off + sizeof(DevCounters) * RT_COUNTER_COPIES, 256);
 	w.qcount = reinterpret_cast<unsigned *>(base + off);       off = align_up(off + 128 * sizeof(unsigned), 256);
 	w.bounce.bounds = reinterpret_cast<unsigned *>(base + off); off = align_up(off + 8 * sizeof(unsigned), 256);
 	w.bounce.sums = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + RT_SCAN_MAX_SEGMENTS * sizeof(unsigned), 256);

@@ -38,6 +38,12 @@ namespace {
 // Kernels
 // =============================================================================
 
+// the counter copy this workgroup adds its ray counts to
+DEV DevCounters *counters_of_block(DevCounters *counters)
+{
+	return counters + (blockIdx.x & (RT_COUNTER_COPIES - 1));
+}
+
 // entries of the slice that exist
 DEV unsigned slice_count(const QueueSlice &q)
 {
@@ -204,11 +210,12 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		}
 	}
 	const u64 active_lanes = __builtin_amdgcn_ballot_w64(tactive), env_lanes = __builtin_amdgcn_ballot_w64(n_env != 0);
+	DevCounters *mine = counters_of_block(counters);
 	if (lane == 0) {
-		if (active_lanes) atomicAdd(&counters->rays_primary, (unsigned long long)__builtin_popcountll(active_lanes));
-		if (env_lanes) atomicAdd(&counters->env_lookups, (unsigned long long)__builtin_popcountll(env_lanes));
+		if (active_lanes) atomicAdd(&mine->rays_primary, (unsigned long long)__builtin_popcountll(active_lanes));
+		if (env_lanes) atomicAdd(&mine->env_lookups, (unsigned long long)__builtin_popcountll(env_lanes));
 	}
-	wave_count_add(&counters->rays_shadow, n_shadow);
+	wave_count_add(&mine->rays_shadow, n_shadow);
 	TM_END(TM_TAIL, t_tail);
 	TM_END(TM_KERNEL, t_kernel);
 #ifdef RT_TIMING
@@ -285,9 +292,9 @@ k_bounce(DevScene sc, QueueSlice in, unsigned queue_capacity,
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}
-	wave_count_add(&counters->rays_secondary, n_rays);
-	wave_count_add(&counters->rays_shadow, n_shadow);
-	wave_count_add(&counters->env_lookups, n_env);
+	wave_count_add(&counters_of_block(counters)->rays_secondary, n_rays);
+	wave_count_add(&counters_of_block(counters)->rays_shadow, n_shadow);
+	wave_count_add(&counters_of_block(counters)->env_lookups, n_env);
 	TM_END(TM_KERNEL, t_kernel);
 #ifdef RT_TIMING
 	if ((threadIdx.x & 63) < TM_COUNT)
@@ -393,8 +400,8 @@ k_bounce_trace(DevScene sc, QueueSlice in, long long *accum, BounceHit *bhit, un
 			atomicMin(&bounds[3 + a], ~float_to_ordered(hi[a]));
 		}
 	}
-	wave_count_add(&counters->rays_secondary, n_rays);
-	wave_count_add(&counters->env_lookups, n_env);
+	wave_count_add(&counters_of_block(counters)->rays_secondary, n_rays);
+	wave_count_add(&counters_of_block(counters)->env_lookups, n_env);
 }
 
 DEV unsigned spread3(unsigned v)
@@ -638,7 +645,7 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, u
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}
-	wave_count_add(&counters->rays_shadow, n_shadow);
+	wave_count_add(&counters_of_block(counters)->rays_shadow, n_shadow);
 	TM_END(TM_KERNEL, t_kernel);
 #ifdef RT_TIMING
 	if ((threadIdx.x & 63) < TM_COUNT)
@@ -713,12 +720,22 @@ k_bounce_shade_small(DevScene sc, const QueueItem *queue_in, const unsigned *n_h
 		if (active)
 			accumulate(accum, slot, cmul(weight, total));
 	}
-	wave_count_add(&counters->rays_shadow, n_shadow);
+	wave_count_add(&counters_of_block(counters)->rays_shadow, n_shadow);
 }
 
-#if defined(RT_TRAVERSAL_STATS) || defined(RT_TIMING)
-__global__ void k_collect_stats(DevCounters *counters)
+// Folds the counter copies into copy 0 (one thread per copy) and clears them.
+__global__ void __launch_bounds__(RT_COUNTER_COPIES)
+k_collect_stats(DevCounters *counters)
 {
+	if (threadIdx.x > 0) {
+		DevCounters *c = counters + threadIdx.x;
+		if (c->rays_primary) atomicAdd(&counters->rays_primary, c->rays_primary);
+		if (c->rays_shadow) atomicAdd(&counters->rays_shadow, c->rays_shadow);
+		if (c->rays_secondary) atomicAdd(&counters->rays_secondary, c->rays_secondary);
+		if (c->env_lookups) atomicAdd(&counters->env_lookups, c->env_lookups);
+		c->rays_primary = c->rays_shadow = c->rays_secondary = c->env_lookups = 0;
+		return;
+	}
 #ifdef RT_TRAVERSAL_STATS
 	counters->bvh_nodes = g_stat_nodes;
 	counters->tri_tests = g_stat_tris;
@@ -743,7 +760,6 @@ __global__ void k_collect_stats(DevCounters *counters)
 	}
 #endif
 }
-#endif
 
 // The reference's rand() stream (ray.c:14-17 after srand, raytracer.c:74) for a run
 // of draws, generated where it is used.  The generator is linear: its raw values
@@ -1051,16 +1067,12 @@ hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, u
 	return hipGetLastError();
 }
 
-// Build options only: moves the traversal statistics into the counter block.
+// Folds the counter copies into the first one (and, in statistics builds, moves the
+// traversal statistics there).
 hipError_t rt_launch_collect_stats(DevCounters *counters, hipStream_t stream)
 {
-#if defined(RT_TRAVERSAL_STATS) || defined(RT_TIMING)
-	hipLaunchKernelGGL(k_collect_stats, dim3(1), dim3(1), 0, stream, counters);
+	hipLaunchKernelGGL(k_collect_stats, dim3(1), dim3(RT_COUNTER_COPIES), 0, stream, counters);
 	return hipGetLastError();
-#else
-	(void)counters; (void)stream;
-	return hipSuccess;
-#endif
 }
 
 hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,

@@ -175,7 +175,14 @@ struct GlibcJump {
 	uint32_t c[RT_GLIBC_POLY];
 };
 
-struct DevCounters {
+/* The counter block exists RT_COUNTER_COPIES times, 128 bytes apart.  A wave adds
+ * its ray counts to the copy its workgroup number selects, so that the millions of
+ * waves of a frame do not queue up on four addresses (atomics on one address are
+ * worked off one after the other, a few nanoseconds each: at 4K x 64 spp that
+ * alone was most of a frame of planes).  Copy 0 also holds the rare events
+ * (overflow, peak); k_collect_stats folds the others into it. */
+#define RT_COUNTER_COPIES 256
+struct __attribute__((aligned(128))) DevCounters {
 	unsigned long long rays_primary, rays_shadow, rays_secondary, env_lookups;
 	unsigned long long queue_overflow;
 	unsigned long long queue_peak;

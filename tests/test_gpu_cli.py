@@ -107,6 +107,17 @@ def test_overrides_bands_and_devices(tmp_path):
     assert np.abs(s.astype(int) - a.astype(int)).mean() < 3.0      # another sample set, the same picture
     r = run_cli(tmp_path, scene, *base[:-2], "--no-aa", "-o", "n.ppm")
     assert r.returncode == 0 and not np.array_equal(read_ppm(os.path.join(str(tmp_path), "n.ppm")), a)
+    # a .png name selects the PNG writer: the same pixels as the PPM
+    import struct
+    import zlib
+    r = run_cli(tmp_path, scene, *base, "-o", "a.png")
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = open(os.path.join(str(tmp_path), "a.png"), "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and data[12:16] == b"IHDR"
+    n = struct.unpack(">I", data[33:37])[0]
+    assert data[37:41] == b"IDAT"
+    rows = np.frombuffer(zlib.decompress(data[41:41 + n]), np.uint8).reshape(80, 1 + 3 * 96)
+    assert np.array_equal(rows[:, 1:].reshape(80, 96, 3), a)
     assert run_cli(tmp_path, scene, "--frobnicate").returncode == 1
     assert run_cli(tmp_path, scene, *base, "--device", "99").returncode == 1
 
