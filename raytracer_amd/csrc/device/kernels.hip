@@ -187,27 +187,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	} else {
 		// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
 		// not depend on the order in which lanes, waves or later bounces arrive.
-		long long r = tactive ? to_fixed(total.r) : 0, g = tactive ? to_fixed(total.g) : 0,
-		     b = tactive ? to_fixed(total.b) : 0;
-		// segmented reduction over runs of lanes that share a pixel (runs are contiguous)
-		uint32_t seg = tactive ? tslot : 0xffffffffu;
-		for (int off = 1; off < 64; off <<= 1) {
-			uint32_t oseg = __shfl_down(seg, off, 64);
-			long long orr = __shfl_down(r, off, 64), og = __shfl_down(g, off, 64), ob = __shfl_down(b, off, 64);
-			// lane + off belongs to my run only if every lane in between does, which holds
-			// for contiguous runs when its slot equals mine
-			if (lane + off < 64 && oseg == seg) {
-				r += orr; g += og; b += ob;
-			}
-		}
-		uint32_t prev = __shfl_up(seg, 1, 64);
-		bool head = tactive && (lane == 0 || prev != seg);
-		if (head) {
-			unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * tslot);
-			if (r) atomicAdd(p + 0, (unsigned long long)r);
-			if (g) atomicAdd(p + 1, (unsigned long long)g);
-			if (b) atomicAdd(p + 2, (unsigned long long)b);
-		}
+		accumulate_runs(accum, tslot, total, tactive);
 	}
 	const u64 active_lanes = __builtin_amdgcn_ballot_w64(tactive), env_lanes = __builtin_amdgcn_ballot_w64(n_env != 0);
 	DevCounters *mine = counters_of_block(counters);
@@ -289,8 +269,8 @@ k_bounce(DevScene sc, QueueSlice in, unsigned queue_capacity,
 			return d3{ dq[0], dq[1], dq[2] };
 		};
 		c3 total = shade_vertex<RT_BOUNCE_PACKET != 0, RT_BOUNCE_TRANSPOSE != 0>(io, ray, depth, key, weight, slot, active, stack, nullptr, n_shadow, n_env, ray_again);
-		if (active)
-			accumulate(accum, slot, cmul(weight, total));
+		// queue order is pixel order: the lanes of a wave mostly share a pixel
+		accumulate_runs(accum, slot, cmul(weight, total), active);
 	}
 	wave_count_add(&counters_of_block(counters)->rays_secondary, n_rays);
 	wave_count_add(&counters_of_block(counters)->rays_shadow, n_shadow);
@@ -355,11 +335,16 @@ k_bounce_trace(DevScene sc, QueueSlice in, long long *accum, BounceHit *bhit, un
 	const unsigned rounds = (count + stride - 1) / stride;
 	for (unsigned round = 0; round < rounds; round++) {
 		const unsigned idx = round * stride + blockIdx.x * RT_BLOCK + threadIdx.x;
-		if (idx >= count)
-			continue;
-		const QueueItem it = queue_in[idx];
+		const bool present = idx < count;
+		QueueItem it;
+		it.depth = QUEUE_SLOT_UNUSED;
+		it.slot = 0;
+		if (present)
+			it = queue_in[idx];
 		BounceHit h;
 		h.surface = -1; h.tri = -1; h.ncode = 0; h.t = 0; h.a = h.b = h.c = 0; h.pad = 0;
+		bool missed = false;
+		c3 escaped = { 0.0f, 0.0f, 0.0f };
 		if (it.depth != QUEUE_SLOT_UNUSED) {
 			Ray ray;
 			ray.o = { it.o[0], it.o[1], it.o[2] };
@@ -385,10 +370,13 @@ k_bounce_trace(DevScene sc, QueueSlice in, long long *accum, BounceHit *bhit, un
 					n_env++;
 				} else
 					total = lc3(sc.background);
-				accumulate(accum, it.slot, cmul({ it.weight[0], it.weight[1], it.weight[2] }, total));
+				missed = true;
+				escaped = cmul({ it.weight[0], it.weight[1], it.weight[2] }, total);
 			}
 		}
-		bhit[idx] = h;
+		accumulate_runs(accum, it.slot, escaped, missed);
+		if (present)
+			bhit[idx] = h;
 	}
 	for (int a = 0; a < 3; a++) {
 		for (int off = 32; off > 0; off >>= 1) {
@@ -642,8 +630,7 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, u
 		};
 		const c3 total = shade_hit<false, false>(io, active, surface, position, normal, ray_d, depth, key, weight, slot,
 				stack, n_shadow, ray_again);
-		if (active)
-			accumulate(accum, slot, cmul(weight, total));
+		accumulate_runs(accum, slot, cmul(weight, total), active);
 	}
 	wave_count_add(&counters_of_block(counters)->rays_shadow, n_shadow);
 	TM_END(TM_KERNEL, t_kernel);
@@ -717,8 +704,7 @@ k_bounce_shade_small(DevScene sc, const QueueItem *queue_in, const unsigned *n_h
 		};
 		const c3 total = shade_hit<false, true>(io, active, surface, position, normal, ray_d, depth, key, weight, slot,
 				stack, n_shadow, ray_again);
-		if (active)
-			accumulate(accum, slot, cmul(weight, total));
+		accumulate_runs(accum, slot, cmul(weight, total), active);
 	}
 	wave_count_add(&counters_of_block(counters)->rays_shadow, n_shadow);
 }

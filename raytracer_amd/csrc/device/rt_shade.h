@@ -106,9 +106,42 @@ DEV void accumulate(long long *accum, uint32_t slot, c3 c)
 {
 	unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
 	long long r = to_fixed(c.r), g = to_fixed(c.g), b = to_fixed(c.b);
+#ifdef RT_EXPERIMENT_NO_ACCUM
+	if (c.r != -12345.0f) return;
+#endif
 	if (r) atomicAdd(p + 0, (unsigned long long)r);
 	if (g) atomicAdd(p + 1, (unsigned long long)g);
 	if (b) atomicAdd(p + 2, (unsigned long long)b);
+}
+
+// The same for every lane of a wave at once (all 64 lanes must call; `on` says which
+// ones have something to add).  Neighbouring lanes that add to the same pixel are
+// summed first and the first lane of the run issues the three atomics: integer adds
+// commute, so the pixel ends up with the same bits, and a wave whose lanes hold the
+// samples of one pixel sends 3 atomics instead of 192 to one address.
+DEV void accumulate_runs(long long *accum, uint32_t slot, c3 c, bool on)
+{
+	long long r = on ? to_fixed(c.r) : 0, g = on ? to_fixed(c.g) : 0, b = on ? to_fixed(c.b) : 0;
+	const unsigned lane = lane_id();
+	const uint32_t seg = on ? slot : 0xffffffffu;
+	const uint32_t prev = __shfl_up(seg, 1, 64);
+	const bool first = lane == 0 || prev != seg;
+	// the lane a run starts at names the run
+	const u64 firsts = __builtin_amdgcn_ballot_w64(first);
+	const unsigned start = 63u - (unsigned)__builtin_clzll(firsts & (~0ull >> (63u - lane)));
+	for (int off = 1; off < 64; off <<= 1) {
+		const unsigned ostart = __shfl_down(start, off, 64);
+		const long long orr = __shfl_down(r, off, 64), og = __shfl_down(g, off, 64), ob = __shfl_down(b, off, 64);
+		if (lane + off < 64 && ostart == start) {
+			r += orr; g += og; b += ob;
+		}
+	}
+	if (on && first) {
+		unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
+		if (r) atomicAdd(p + 0, (unsigned long long)r);
+		if (g) atomicAdd(p + 1, (unsigned long long)g);
+		if (b) atomicAdd(p + 2, (unsigned long long)b);
+	}
 }
 
 // What a path vertex needs besides its ray.
