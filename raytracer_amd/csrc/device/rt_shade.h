@@ -106,9 +106,6 @@ DEV void accumulate(long long *accum, uint32_t slot, c3 c)
 {
 	unsigned long long *p = reinterpret_cast<unsigned long long *>(accum + 3ull * slot);
 	long long r = to_fixed(c.r), g = to_fixed(c.g), b = to_fixed(c.b);
-#ifdef RT_EXPERIMENT_NO_ACCUM
-	if (c.r != -12345.0f) return;
-#endif
 	if (r) atomicAdd(p + 0, (unsigned long long)r);
 	if (g) atomicAdd(p + 1, (unsigned long long)g);
 	if (b) atomicAdd(p + 2, (unsigned long long)b);
