@@ -403,7 +403,10 @@ DEV unsigned spread3(unsigned v)
 }
 
 // Bin of every hit: Morton code of its cell in a (2^bits)^3 grid over the bounds
-// of this level's hit points; misses and unused slots go to the extra last bin.
+// of this level's hit points.  Misses and unused slots carry the number of the extra
+// last bin and take no rank: that bin's scanned offset is the number of hits, its
+// own population is never needed, and every wave adding to it would queue on one
+// address.
 __global__ void k_bounce_bin(QueueSlice in, const BounceHit *bhit, const unsigned *bounds, unsigned *hist,
 		BounceBin *bbin, int bits)
 {
@@ -439,20 +442,29 @@ __global__ void k_bounce_bin(QueueSlice in, const BounceHit *bhit, const unsigne
 		// Neighbouring queue entries are children of one pixel and mostly land in the
 		// same bin: the lanes of a wave that share a key take their ranks from ONE
 		// atomic (thousands of single increments on one address serialise in L2).
-		unsigned rank = 0;
-		u64 todo = __builtin_amdgcn_ballot_w64(active);
+		// First the lanes sort themselves into groups of equal keys (no memory access),
+		// then the first lane of every group reserves the group's ranks: one atomic
+		// instruction per wave and turn, whose round trip is waited for once.
+		unsigned first_lane = 0, before = 0, group = 0;
+		const unsigned no_bin = 1u << (3 * bits);
+		const bool ranked = active && key != no_bin;
+		u64 todo = __builtin_amdgcn_ballot_w64(ranked);
 		while (todo) {
 			const int leader = __builtin_ctzll(todo);
 			const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
-			const u64 same = __builtin_amdgcn_ballot_w64(active && key == k) & todo;
-			unsigned base = 0;
-			if ((int)lane_id() == leader)
-				base = atomicAdd(&hist[k], (unsigned)__builtin_popcountll(same));
-			base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-			if (active && key == k)
-				rank = base + (unsigned)__builtin_popcountll(same & ((1ull << lane_id()) - 1ull));
+			const u64 same = __builtin_amdgcn_ballot_w64(ranked && key == k) & todo;
+			if (ranked && key == k) {
+				first_lane = (unsigned)leader;
+				before = (unsigned)__builtin_popcountll(same & ((1ull << lane_id()) - 1ull));
+				group = (unsigned)__builtin_popcountll(same);
+			}
 			todo &= ~same;
 		}
+		unsigned base = 0;
+		if (ranked && lane_id() == first_lane)
+			base = atomicAdd(&hist[key], group);
+		base = (unsigned)__shfl((int)base, (int)first_lane, 64);
+		const unsigned rank = base + before;
 		if (active) {
 			BounceBin b;
 			b.key = key;
@@ -544,13 +556,15 @@ k_scan_segments(unsigned *hist, unsigned n, const unsigned *sums)
 	}
 }
 
-__global__ void k_bounce_scatter(QueueSlice in, const BounceBin *bbin, const unsigned *offsets, unsigned *perm)
+__global__ void k_bounce_scatter(QueueSlice in, const BounceBin *bbin, const unsigned *offsets, unsigned *perm,
+		unsigned no_bin)
 {
 	const unsigned count = slice_count(in);
 	const unsigned stride = gridDim.x * blockDim.x;
 	for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += stride) {
 		const BounceBin b = bbin[idx];
-		perm[offsets[b.key] + b.rank] = idx;
+		if (b.key != no_bin)
+			perm[offsets[b.key] + b.rank] = idx;
 	}
 }
 
@@ -1010,7 +1024,8 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, lon
 		unsigned *queue_out_count, DevCounters *counters, const BounceWork &work, unsigned grid_blocks,
 		hipStream_t stream)
 {
-	const unsigned n_bins = (1u << (3 * work.bits)) + 1u;
+	const int bits = work.bits;
+	const unsigned n_bins = (1u << (3 * bits)) + 1u;
 	const unsigned n_seg = (n_bins + RT_SCAN_SEGMENT - 1) / RT_SCAN_SEGMENT;
 	hipError_t e;
 	if ((e = hipMemsetAsync(work.hist, 0, (size_t)n_bins * sizeof(unsigned), stream)) != hipSuccess) return e;
@@ -1018,11 +1033,12 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, lon
 	hipLaunchKernelGGL(k_bounce_trace, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, in, accum, work.hits,
 			work.bounds, counters);
 	hipLaunchKernelGGL(k_bounce_bin, dim3(grid_blocks), dim3(256), 0, stream, in, work.hits, work.bounds, work.hist,
-			work.bins, work.bits);
+			work.bins, bits);
 	hipLaunchKernelGGL(k_scan_sums, dim3(n_seg), dim3(256), 0, stream, work.hist, n_bins, work.sums);
 	hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, stream, work.sums, n_seg);
 	hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(256), 0, stream, work.hist, n_bins, work.sums);
-	hipLaunchKernelGGL(k_bounce_scatter, dim3(grid_blocks), dim3(256), 0, stream, in, work.bins, work.hist, work.perm);
+	hipLaunchKernelGGL(k_bounce_scatter, dim3(grid_blocks), dim3(256), 0, stream, in, work.bins, work.hist, work.perm,
+			n_bins - 1u);
 	// levels of fewer hits than the GPU has lanes to give them are shaded by the kernel
 	// that spreads each hit's light samples over a wave
 	const unsigned small_below = work.small_below;
