@@ -425,11 +425,7 @@ DEV c3 shade_hit(const ShadeIO &io, bool lit, int surface, d3 position, d3 norma
 				Best dummy;
 				TM_END(TM_LIGHT_SETUP, t_lsetup);
 				TM_BEGIN(t_shadow);
-#ifdef RT_EXPERIMENT_NO_SIMT_SHADOWS
-				const bool occluded = PACKET ? trace<true, PACKET>(sc, shadow, stack, dummy, shaft_state) : false;
-#else
 				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy, shaft_state);
-#endif
 				TM_END(TM_TRACE_SHADOW, t_shadow);
 				if (occluded)
 					continue;

@@ -1,5 +1,5 @@
 """Host-built (SAH) against device-built (linear) BVH on the benchmark scene: build
-times per mesh and frame time, printed for DESIGN.md."""
+times per mesh and frame time, printed as a table."""
 import ctypes as C
 import os
 import sys
