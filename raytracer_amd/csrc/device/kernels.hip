@@ -56,12 +56,21 @@ DEV unsigned slice_count(const QueueSlice &q)
 
 // Primary samples: camera ray, nearest hit, direct lighting with shadow rays,
 // environment lookup; children go to the bounce queue.  raytracer.c:32-54,78-84.
-// Register budget: the primary kernel runs at four waves per SIMD (128 VGPRs, 12
-// spilled dwords per lane; three and five waves both measured about 15 % slower on
-// the 1080p showcase frame); the bounce kernels keep per-lane stacks in LDS (32 KB
-// per workgroup) and run at four as well.
+// Register budget: the primary kernel exists for four waves per SIMD (128 VGPRs, 12
+// spilled dwords per lane) and for five (96 VGPRs, 47 spilled dwords).  The kernel is
+// bound by the latency of a wave's own instruction stream as much as by the vector
+// issue rate: three waves measure 16 % slower than four on the 4K showcase frame, and
+// removing 3 % of the vector instructions changes nothing.  Five waves pay where a
+// sample's shadow loops are long (scenes that sample area lights: showcase -1.3 %,
+// 6-soft -5 %, 7-reflections -6 %) and cost where they are not (3-aa +3 %, the five
+// planes of cornell +6 %), six waves are slower everywhere; the launcher picks by
+// that.  The bounce kernels keep per-lane stacks in LDS (32 KB per workgroup) and run
+// at four.
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
+#endif
+#ifndef RT_MIN_WAVES_LONG
+#define RT_MIN_WAVES_LONG 5
 #endif
 #ifndef RT_MIN_WAVES_BOUNCE
 #define RT_MIN_WAVES_BOUNCE 4
@@ -73,7 +82,8 @@ DEV unsigned slice_count(const QueueSlice &q)
 #define RT_BOUNCE_TRANSPOSE 1
 #endif
 
-__global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES)
+template <int WAVES>
+__global__ void __launch_bounds__(RT_BLOCK, WAVES)
 k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
 		int rng_mode, uint32_t seed, GlibcTable glibc_table, long long *accum, float *direct_out,
 		rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count, unsigned queue_capacity,
@@ -1005,9 +1015,14 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		return hipSuccess;
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long blocks = (sample_count + RT_BLOCK - 1) / RT_BLOCK;
-	hipLaunchKernelGGL(k_primary, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm, sample_first,
-			sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out, queue_count,
-			queue_capacity, counters);
+	if (sc.any_area_light)
+		hipLaunchKernelGGL(k_primary<RT_MIN_WAVES_LONG>, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm,
+				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out,
+				queue_count, queue_capacity, counters);
+	else
+		hipLaunchKernelGGL(k_primary<RT_MIN_WAVES>, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm,
+				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out,
+				queue_count, queue_capacity, counters);
 	return hipGetLastError();
 }
 
