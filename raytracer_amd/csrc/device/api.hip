@@ -318,6 +318,9 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	sc->glossy = any_glossy;
 	d.any_reflective = any_reflective && h.max_reflections >= 1;
 	d.any_area_light = any_area && h.shadow_samples >= 2;
+	d.shadow_rays_per_hit = 0;
+	for (int i = 0; i < h.num_lights; i++)
+		d.shadow_rays_per_hit += bl[i].type == RTAMD_LIGHT_AREA ? h.shadow_samples * h.shadow_samples : 1;
 
 	// Meshes: leaf-ordered triangle and normal arrays, one BVH each.
 	std::vector<DevMesh> meshes(h.num_meshes);

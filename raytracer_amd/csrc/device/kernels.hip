@@ -61,16 +61,20 @@ DEV unsigned slice_count(const QueueSlice &q)
 // bound by the latency of a wave's own instruction stream as much as by the vector
 // issue rate: three waves measure 16 % slower than four on the 4K showcase frame, and
 // removing 3 % of the vector instructions changes nothing.  Five waves pay where a
-// sample's shadow loops are long (scenes that sample area lights: showcase -1.3 %,
-// 6-soft -5 %, 7-reflections -6 %) and cost where they are not (3-aa +3 %, the five
-// planes of cornell +6 %), six waves are slower everywhere; the launcher picks by
-// that.  The bounce kernels keep per-lane stacks in LDS (32 KB per workgroup) and run
+// sample's shadow loops are long (6-soft with 48 shadow rays per hit -5 %,
+// 7-reflections with 50 -6 %, the showcase with 17 -1 %, at the price of 200 GB of
+// spill traffic per 4K frame) and cost where they are short (3-aa +3 %, the five
+// planes of cornell +6 %), six waves are slower everywhere; the launcher takes the
+// five-wave form from RT_LONG_SHADOW_LOOPS shadow rays per hit.  The bounce kernels keep per-lane stacks in LDS (32 KB per workgroup) and run
 // at four.
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
 #ifndef RT_MIN_WAVES_LONG
 #define RT_MIN_WAVES_LONG 5
+#endif
+#ifndef RT_LONG_SHADOW_LOOPS
+#define RT_LONG_SHADOW_LOOPS 32
 #endif
 #ifndef RT_MIN_WAVES_BOUNCE
 #define RT_MIN_WAVES_BOUNCE 4
@@ -1015,7 +1019,7 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		return hipSuccess;
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long blocks = (sample_count + RT_BLOCK - 1) / RT_BLOCK;
-	if (sc.any_area_light)
+	if (sc.any_area_light && sc.shadow_rays_per_hit >= RT_LONG_SHADOW_LOOPS)
 		hipLaunchKernelGGL(k_primary<RT_MIN_WAVES_LONG>, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm,
 				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out,
 				queue_count, queue_capacity, counters);

@@ -104,7 +104,8 @@ struct DevScene {
 	float cam_d;               /* `d = near` narrowed to float, ray.c:32 */
 	float background[3];
 	int32_t num_lights, num_surfaces, has_cubemap, any_reflective;
-	int32_t any_area_light, pad0;
+	int32_t any_area_light;
+	int32_t shadow_rays_per_hit; /* point lights + shadow_samples^2 per area light */
 	const DevLight *lights;
 	const DevSurface *surfaces;
 	const DevMaterial *materials;

@@ -25,7 +25,9 @@ tot = defaultdict(float)
 disp = defaultdict(set)
 for path in sorted(glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv"))):
     for row in csv.DictReader(open(path)):
-        if row["Kernel_Name"].split("(")[0] != kernel:
+        # "k_primary(...)" or the template form "void k_primary<5>(...)"
+        name = row["Kernel_Name"].split("(")[0].split("<")[0].split()[-1]
+        if name != kernel:
             continue
         tot[row["Counter_Name"]] += float(row["Counter_Value"])
         disp[row["Counter_Name"]].add(row["Dispatch_Id"])
