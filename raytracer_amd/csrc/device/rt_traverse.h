@@ -256,14 +256,13 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 			const u64 m0 = __builtin_amdgcn_ballot_w64(h0) & actm;
 			const u64 m1 = __builtin_amdgcn_ballot_w64(h1) & actm;
 			const int c0 = as_i(q3.x), c1 = as_i(q3.y);
-			bool swap = false;
-			if (!ANYHIT) {
-				// front-to-back for the majority of the lanes
-				const u64 pref1 = __builtin_amdgcn_ballot_w64(tn1 < tn0);
-				const u64 both = m0 & m1;
-				const u64 w1 = (both & pref1) | (m1 & ~m0), w0 = (both & ~pref1) | (m0 & ~m1);
-				swap = __builtin_popcountll(w1) > __builtin_popcountll(w0);
-			}
+			// front-to-back for the majority of the lanes; for shadow rays any order finds
+			// the same answer, but lanes whose ray is blocked drop out sooner when the near
+			// child comes first (7-reflections and 6-soft -2.5 %)
+			const u64 pref1 = __builtin_amdgcn_ballot_w64(tn1 < tn0);
+			const u64 both = m0 & m1;
+			const u64 w1 = (both & pref1) | (m1 & ~m0), w0 = (both & ~pref1) | (m0 & ~m1);
+			const bool swap = __builtin_popcountll(w1) > __builtin_popcountll(w0);
 			u64 nm = swap ? m1 : m0, fm = swap ? m0 : m1;
 			int nc = swap ? c1 : c0, fc = swap ? c0 : c1;
 			if (nm == 0) {
