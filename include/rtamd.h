@@ -272,6 +272,11 @@ int rtamd_render(rtamd_scene *scene, const rtamd_render_params *params,
  * bytes per owned pixel) and at least one workgroup's worth of queued rays must
  * fit into the array, and so must the rand() draws of one row of tiles in the
  * RTAMD_RNG_GLIBC mode with antialiasing (8 Mi draws at most).
+ * Under stream capture: in the RTAMD_RNG_GLIBC mode with antialiasing the first
+ * call for a seed (and the first after a call with another mode) uploads the
+ * stream's jump tables from host memory and synchronises the stream, which capture
+ * does not allow; that call returns RTAMD_ERR_ARG on a capturing stream.  Make one
+ * call with the seed outside capture first.  RTAMD_RNG_KEYED has no such state.
  * Calls on one GPU share the array: calls that overlap in time (other streams,
  * other scenes) race; serialise them.  A queue overflow is reported by the next
  * render call on the scene or by rtamd_scene_destroy. */
@@ -305,6 +310,11 @@ int rtamd_tiles_unpack(int width, int height, const rtamd_render_params *params,
 /* Seconds rtamd_scene_create spent on mesh `mesh`'s acceleration structure (the
  * figure behind the reference's "Building kd-tree took ..." line, scene.c:663-666). */
 int rtamd_scene_mesh_build_seconds(const rtamd_scene *scene, int mesh, double *seconds);
+/* Whether mesh `mesh`'s hierarchy is the one built by the GPU kernels (1) or by the
+ * host's builder (0): the host builds meshes below 2^18 triangles, and any mesh whose
+ * GPU-built tree came out deeper than the traversal stack.  Takes the place of the
+ * reference's single kd-tree builder (mesh.c:417-451); no effect on results. */
+int rtamd_scene_mesh_built_on_device(const rtamd_scene *scene, int mesh, int *on_device);
 int rtamd_scene_dims(const rtamd_scene *scene, int *width, int *height, int *spp);
 const char *rtamd_last_error(void);
 const char *rtamd_version(void);

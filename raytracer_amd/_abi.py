@@ -126,6 +126,7 @@ PROTOTYPES = {
                                      C.c_void_p, C.c_void_p]),
     "rtamd_last_cubemap_load_seconds": (C.c_double, []),
     "rtamd_scene_mesh_build_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "rtamd_scene_mesh_built_on_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "rtamd_scene_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int)]),
     "rtamd_last_error": (C.c_char_p, []),

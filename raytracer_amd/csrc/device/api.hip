@@ -59,6 +59,7 @@ struct rtamd_scene {
 	uint32_t *d_glibc_window = nullptr;          // RT_GLIBC_BLOCK + 31 words, for window_seed
 	uint32_t glibc_window_seed = 0;
 	bool glibc_window_valid = false;
+	bool glibc_powers_uploaded = false;
 	long long *d_accum = nullptr;
 	unsigned long long accum_slots = 0;
 	QueueItem *d_queue[3] = { nullptr, nullptr, nullptr };   // level 1; deeper levels alternate between the other two
@@ -71,6 +72,7 @@ struct rtamd_scene {
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	int device = -1;             // the device the scene's buffers live on
 	std::vector<double> mesh_build_seconds;
+	std::vector<char> mesh_built_on_device;   // per mesh: its tree is the GPU-built one
 	unsigned queue_capacity_max = 0;
 	unsigned overflow_test_capacity = 0;
 	// queue-overflow count of the last asynchronous render, in host-visible memory
@@ -108,6 +110,38 @@ double dot3(const double a[3], const double b[3])                 // vector.c:31
 bool float_valued(double v)
 {
 	return (double)(float)v == v;
+}
+
+// Triangles, corner normals and edge records of one mesh in the leaf order of a
+// host-built tree.  pos / nrm: 9 floats per triangle in the mesh's own order.
+void emit_leaf_ordered(const float *pos, const float *nrm, int nt, const BvhResult &bvh,
+		std::vector<DevTriangle> &tris, std::vector<DevTriangle> &normals, std::vector<DevTriEdges> &edges)
+{
+	for (int i = 0; i < nt; i++) {
+		int orig = bvh.order[i];
+		DevTriangle tp, tn;
+		std::memset(&tp, 0, sizeof tp);
+		std::memset(&tn, 0, sizeof tn);
+		for (int c = 0; c < 3; c++)
+			for (int a = 0; a < 3; a++) {
+				tp.v[4 * c + a] = pos[9 * (size_t)orig + 3 * c + a];
+				tn.v[4 * c + a] = nrm[9 * (size_t)orig + 3 * c + a];
+			}
+		std::memcpy(&tp.v[3], &orig, 4);
+		tris.push_back(tp);
+		normals.push_back(tn);
+		DevTriEdges te;
+		std::memset(&te, 0, sizeof te);
+		for (int a = 0; a < 3; a++) {
+			// vec3_sub(v, u), vec3_sub(w, u): ray.c:334-335, vector.c:21-29
+			const double u = pos[9 * (size_t)orig + a];
+			te.u[a] = u;
+			te.e1[a] = (double)pos[9 * (size_t)orig + 3 + a] - u;
+			te.e2[a] = (double)pos[9 * (size_t)orig + 6 + a] - u;
+		}
+		te.orig = orig;
+		edges.push_back(te);
+	}
 }
 
 } // namespace
@@ -332,10 +366,16 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	// host's SAH build (about a microsecond per triangle and level) starts to cost
 	// more than the frames it speeds up.
 	const char *bvh_mode = getenv("RTAMD_BVH");
+	int device_min = 1 << 18;
+	if (const char *dm = getenv("RTAMD_BVH_DEVICE_MIN")) {      // test knob: the threshold itself
+		const int v = atoi(dm);
+		if (v >= 1)
+			device_min = v;
+	}
 	auto device_build = [&](int ntri) {
 		if (bvh_mode && !strcmp(bvh_mode, "device")) return true;
 		if (bvh_mode && !strcmp(bvh_mode, "host")) return false;
-		return ntri >= (1 << 18);
+		return ntri >= device_min;
 	};
 	struct PendingBuild {
 		int mesh;
@@ -368,11 +408,13 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 				rtamd_set_error("mesh %d: normal component is not a float value", m);
 				return RTAMD_ERR_ARG;
 			}
-		std::vector<float> pos(9 * (size_t)nt);
+		std::vector<float> pos(9 * (size_t)nt), nrm(9 * (size_t)nt);
 		for (int i = 0; i < nt; i++)
 			for (int c = 0; c < 3; c++)
-				for (int a = 0; a < 3; a++)
+				for (int a = 0; a < 3; a++) {
 					pos[9 * (size_t)i + 3 * c + a] = (float)v[3 * (size_t)t[6 * i + c] + a];
+					nrm[9 * (size_t)i + 3 * c + a] = (float)n[3 * (size_t)t[6 * i + 3 + c] + a];
+				}
 		DevMesh &dm = meshes[m];
 		dm.node_first = (int32_t)nodes.size();
 		dm.tri_first = (int32_t)tris.size();
@@ -382,11 +424,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 			PendingBuild pb;
 			pb.mesh = m;
 			pb.pos.swap(pos);
-			pb.nrm.resize(9 * (size_t)nt);
-			for (int i = 0; i < nt; i++)
-				for (int c = 0; c < 3; c++)
-					for (int a = 0; a < 3; a++)
-						pb.nrm[9 * (size_t)i + 3 * c + a] = (float)n[3 * (size_t)t[6 * i + 3 + c] + a];
+			pb.nrm.swap(nrm);
 			pending.push_back(std::move(pb));
 			nodes.resize(nodes.size() + (size_t)(nt > 1 ? nt - 1 : 1));
 			tris.resize(tris.size() + (size_t)nt);
@@ -406,31 +444,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		}
 		dm.root = bvh.root;
 		nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
-		for (int i = 0; i < nt; i++) {
-			int orig = bvh.order[i];
-			DevTriangle tp, tn;
-			std::memset(&tp, 0, sizeof tp);
-			std::memset(&tn, 0, sizeof tn);
-			for (int c = 0; c < 3; c++)
-				for (int a = 0; a < 3; a++) {
-					tp.v[4 * c + a] = pos[9 * (size_t)orig + 3 * c + a];
-					tn.v[4 * c + a] = (float)n[3 * (size_t)t[6 * orig + 3 + c] + a];
-				}
-			std::memcpy(&tp.v[3], &orig, 4);
-			tris.push_back(tp);
-			normals.push_back(tn);
-			DevTriEdges te;
-			std::memset(&te, 0, sizeof te);
-			for (int a = 0; a < 3; a++) {
-				// vec3_sub(v, u), vec3_sub(w, u): ray.c:334-335, vector.c:21-29
-				const double u = pos[9 * (size_t)orig + a];
-				te.u[a] = u;
-				te.e1[a] = (double)pos[9 * (size_t)orig + 3 + a] - u;
-				te.e2[a] = (double)pos[9 * (size_t)orig + 6 + a] - u;
-			}
-			te.orig = orig;
-			edges.push_back(te);
-		}
+		emit_leaf_ordered(pos.data(), nrm.data(), nt, bvh, tris, normals, edges);
 	}
 	if (nodes.empty())
 		nodes.emplace_back();
@@ -458,21 +472,66 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	if ((rc = upload(sc, edges, &d.edges))) return rc;
 	if ((rc = upload(sc, texels, &d.texels))) return rc;
 
+	// RTAMD_BVH_MAX_DEPTH (test knob): device-built trees deeper than this are replaced
+	// by the host's tree, as those deeper than the traversal stack always are
+	int depth_limit = RT_MAX_STACK - 2;
+	if (const char *dl = getenv("RTAMD_BVH_MAX_DEPTH")) {
+		const int v = atoi(dl);
+		if (v >= 1 && v < depth_limit)
+			depth_limit = v;
+	}
+	sc->mesh_built_on_device.assign(h.num_meshes, 0);
 	for (const PendingBuild &pb : pending) {
 		const auto build_t0 = std::chrono::steady_clock::now();
-		const float *d_pos = nullptr, *d_nrm = nullptr;
-		if ((rc = upload(sc, pb.pos, &d_pos))) return rc;
-		if ((rc = upload(sc, pb.nrm, &d_nrm))) return rc;
 		DevMesh &dm = meshes[pb.mesh];
+		const int nt = dm.num_triangles;
+		// staging copies of the corners, only read by the build: freed as soon as it returns
+		float *d_pos = nullptr, *d_nrm = nullptr;
+		const size_t bytes = (size_t)nt * 9 * sizeof(float);
+		hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_pos), bytes);
+		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_nrm), bytes);
+		if (e == hipSuccess) e = hipMemcpy(d_pos, pb.pos.data(), bytes, hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(d_nrm, pb.nrm.data(), bytes, hipMemcpyHostToDevice);
 		int root = 0, depth = 0;
-		HIP_TRY(bvh_build_device(d_pos, d_nrm, dm.num_triangles, const_cast<DevBvhNode *>(d.nodes) + dm.node_first,
-				const_cast<DevTriangle *>(d.tris) + dm.tri_first, const_cast<DevTriangle *>(d.normals) + dm.tri_first,
-				const_cast<DevTriEdges *>(d.edges) + dm.tri_first, &root, &depth, nullptr));
-		if (depth > RT_MAX_STACK - 2) {
-			rtamd_set_error("mesh %d: the BVH built on the device is %d levels deep, more than the traversal "
-					"stack holds (%d); set RTAMD_BVH=host", pb.mesh, depth, RT_MAX_STACK - 2);
-			return RTAMD_ERR_LIMIT;
+		if (e == hipSuccess)
+			e = bvh_build_device(d_pos, d_nrm, nt, const_cast<DevBvhNode *>(d.nodes) + dm.node_first,
+					const_cast<DevTriangle *>(d.tris) + dm.tri_first, const_cast<DevTriangle *>(d.normals) + dm.tri_first,
+					const_cast<DevTriEdges *>(d.edges) + dm.tri_first, &root, &depth, nullptr);
+		if (d_pos) (void)hipFree(d_pos);
+		if (d_nrm) (void)hipFree(d_nrm);
+		if (e != hipSuccess) {
+			rtamd_set_error("mesh %d: BVH build on the device failed: %s", pb.mesh, hipGetErrorString(e));
+			return RTAMD_ERR_HIP;
 		}
+		if (depth > depth_limit) {
+			// A radix tree over Morton codes can be deeper than the traversal stack (long runs
+			// of equal or nearly equal codes); the host's builder bounds its depth by falling
+			// back to median splits.  The mesh's reserved ranges are overwritten with its tree.
+			BvhResult bvh;
+			if (!bvh_build_mesh(pb.pos.data(), nt, bvh)) {
+				rtamd_set_error("mesh %d: could not build a BVH within the traversal stack depth", pb.mesh);
+				return RTAMD_ERR_LIMIT;
+			}
+			std::vector<DevTriangle> htris, hnormals;
+			std::vector<DevTriEdges> hedges;
+			emit_leaf_ordered(pb.pos.data(), pb.nrm.data(), nt, bvh, htris, hnormals, hedges);
+			if (bvh.nodes.size() > (size_t)(nt > 1 ? nt - 1 : 1)) {
+				rtamd_set_error("mesh %d: internal error: host tree has %zu nodes for %d triangles", pb.mesh,
+						bvh.nodes.size(), nt);
+				return RTAMD_ERR_LIMIT;
+			}
+			if (!bvh.nodes.empty())
+				HIP_TRY(hipMemcpy(const_cast<DevBvhNode *>(d.nodes) + dm.node_first, bvh.nodes.data(),
+						bvh.nodes.size() * sizeof(DevBvhNode), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(const_cast<DevTriangle *>(d.tris) + dm.tri_first, htris.data(),
+					htris.size() * sizeof(DevTriangle), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(const_cast<DevTriangle *>(d.normals) + dm.tri_first, hnormals.data(),
+					hnormals.size() * sizeof(DevTriangle), hipMemcpyHostToDevice));
+			HIP_TRY(hipMemcpy(const_cast<DevTriEdges *>(d.edges) + dm.tri_first, hedges.data(),
+					hedges.size() * sizeof(DevTriEdges), hipMemcpyHostToDevice));
+			root = bvh.root;
+		} else
+			sc->mesh_built_on_device[pb.mesh] = 1;
 		dm.root = root;
 		sc->mesh_build_seconds[pb.mesh] =
 				std::chrono::duration<double>(std::chrono::steady_clock::now() - build_t0).count();
@@ -557,6 +616,16 @@ extern "C" int rtamd_scene_mesh_build_seconds(const rtamd_scene *sc, int mesh, d
 		return RTAMD_ERR_ARG;
 	}
 	*seconds = sc->mesh_build_seconds[mesh];
+	return 0;
+}
+
+extern "C" int rtamd_scene_mesh_built_on_device(const rtamd_scene *sc, int mesh, int *on_device)
+{
+	if (!sc || !on_device || mesh < 0 || mesh >= (int)sc->mesh_build_seconds.size()) {
+		rtamd_set_error("rtamd_scene_mesh_built_on_device: bad argument");
+		return RTAMD_ERR_ARG;
+	}
+	*on_device = mesh < (int)sc->mesh_built_on_device.size() && sc->mesh_built_on_device[mesh] ? 1 : 0;
 	return 0;
 }
 
@@ -667,20 +736,32 @@ static int ensure_glibc_buffers(rtamd_scene *sc, uint32_t seed, unsigned long lo
 {
 	if (!sc->dev.antialiasing)
 		return 0;
-	const bool had_powers = sc->d_glibc_powers != nullptr;
 	void *p = nullptr;
-	if (!sc->d_glibc_powers) {
-		HIP_TRY(hipMalloc(&p, (size_t)2048 * RT_GLIBC_POLY * sizeof(uint32_t)));
-		sc->d_glibc_powers = static_cast<uint32_t *>(p);
-		HIP_TRY(hipMalloc(&p, (RT_GLIBC_BLOCK + RT_GLIBC_POLY) * sizeof(uint32_t)));
-		sc->d_glibc_window = static_cast<uint32_t *>(p);
+	if (!sc->d_glibc_powers || !sc->d_glibc_window) {
+		// both or neither: a failure of the second allocation must not leave a powers
+		// table that the next call takes for uploaded
+		void *pw = nullptr, *win = nullptr;
+		hipError_t e = hipMalloc(&pw, (size_t)2048 * RT_GLIBC_POLY * sizeof(uint32_t));
+		if (e == hipSuccess)
+			e = hipMalloc(&win, (RT_GLIBC_BLOCK + RT_GLIBC_POLY) * sizeof(uint32_t));
+		if (e != hipSuccess) {
+			if (pw) (void)hipFree(pw);
+			rtamd_set_error("allocating the rand() stream tables failed: %s", hipGetErrorString(e));
+			return RTAMD_ERR_HIP;
+		}
+		sc->d_glibc_powers = static_cast<uint32_t *>(pw);
+		sc->d_glibc_window = static_cast<uint32_t *>(win);
+		sc->glibc_powers_uploaded = false;
+		sc->glibc_window_valid = false;
 	}
+	const bool had_powers = sc->glibc_powers_uploaded;
 	const bool window_ok = sc->glibc_window_valid && sc->glibc_window_seed == seed;
 	if (!window_ok)
 		HIP_TRY(hipStreamSynchronize(stream));     // an earlier fill may still read the old window
 	int rc = glibc_upload_tables(sc, seed, sc->d_glibc_powers, had_powers, sc->d_glibc_window, window_ok, stream);
 	if (rc)
 		return rc;
+	sc->glibc_powers_uploaded = true;
 	sc->glibc_window_seed = seed;
 	sc->glibc_window_valid = true;
 	// the configured size, but never less than one row of tiles needs (if that is allowed at all)
@@ -1133,6 +1214,8 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	if (rc)
 		return rc;
 	const unsigned long long pixels = pix_hi - pix_lo;
+	if (!pixels)
+		return 0;          // an owner without tiles in the window: nothing to render
 	unsigned char *base = (sc->device >= 0 && sc->device < MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;
 	if (!base) {
 		rtamd_set_error("rtamd_render_noalloc: no scratch address for device %d (rtamd_init not called?)",
@@ -1169,8 +1252,19 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		off = align_up(off + (RT_GLIBC_BLOCK + RT_GLIBC_POLY) * sizeof(uint32_t), 256);
 		const bool same_place = st.powers == powers;
 		const bool window_ok = same_place && st.window_valid && st.window_seed == p.seed;
-		if (!window_ok)
+		if (!window_ok) {
+			// The tables are uploaded from host memory with a stream synchronisation, which
+			// a stream under capture does not allow: the first call per seed (and after a
+			// call with another layout) must be made outside capture.
+			hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+			if (stream && hipStreamIsCapturing(stream, &capture) == hipSuccess &&
+					capture != hipStreamCaptureStatusNone) {
+				rtamd_set_error("rtamd_render_noalloc: the rand() stream tables for seed %u are not resident; "
+						"make one call with this seed outside stream capture first", p.seed);
+				return RTAMD_ERR_ARG;
+			}
 			HIP_TRY(hipStreamSynchronize(stream));
+		}
 		if ((rc = glibc_upload_tables(sc, p.seed, powers, same_place, window, window_ok, stream)))
 			return rc;
 		st.powers = powers;
@@ -1206,15 +1300,19 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		const size_t per_entry = 3 * sizeof(QueueItem) + (sorted ? sizeof(BounceHit) + sizeof(BounceBin) + sizeof(unsigned) : 0);
 		size_t cap = (RTAMD_NOALLOC_SCRATCH_BYTES - off - 6 * 256) / per_entry;
 		cap -= cap % 256;
-		const unsigned long long want = pixels * (unsigned)sc->dev.spp * vertex_fan(sc);
+		// as rtamd_render sizes its queues: what the call's samples can spawn, but never
+		// less than the floor that keeps a chunk at a workgroup or more
+		unsigned long long want = pixels * (unsigned)sc->dev.spp * vertex_fan(sc);
+		if (want < QUEUE_CAPACITY_MIN)
+			want = QUEUE_CAPACITY_MIN;
 		if (cap > want)
 			cap = (size_t)align_up((size_t)want, 256);
 		if (cap > sc->queue_capacity_max)
 			cap = sc->queue_capacity_max;
-		if (cap < vertex_fan(sc) * vertex_fan(sc) * RT_BLOCK) {
+		if (cap < vertex_fan(sc) * RT_BLOCK) {
 			rtamd_set_error("rtamd_render_noalloc: the scratch array leaves room for %zu queued rays, fewer "
 					"than one workgroup of samples can spawn (%llu); use rtamd_render", cap,
-					vertex_fan(sc) * vertex_fan(sc) * RT_BLOCK);
+					vertex_fan(sc) * RT_BLOCK);
 			return RTAMD_ERR_LIMIT;
 		}
 		w.queue_capacity = (unsigned)cap;

@@ -72,3 +72,29 @@ def test_noalloc_serial_stream_mode():
     for seed in (0x20071208, 99):
         got, want = frames(render, blob, render.make_params(seed=seed, rng_mode=_abi.RNG_GLIBC))
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_noalloc_accepts_small_calls_like_render_does():
+    """A call whose samples could spawn fewer rays than the queue floor (one 32 x 32 tile
+    of 8-glossy without antialiasing, reflection_samples 8) and an owner without tiles
+    in the frame: rtamd_render renders both, so must the entry point that allocates
+    nothing (its queue capacity is floored the same way, and no pixels is no work)."""
+    import torch
+    from raytracer_amd import render
+    render.init(0)
+    blob = ra.load_sdl(scene_path("8-glossy")).with_config(width=32, height=32, antialiasing=0)
+    assert blob.header.reflection_samples > 4
+    got, want = frames(render, blob, render.make_params(rng_mode=_abi.RNG_KEYED))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert want[..., :3].max() > 0.1
+    # one tile in the frame, owner 1 of 2 has none
+    dev = render.DeviceScene(blob)
+    p = render.make_params(rng_mode=_abi.RNG_KEYED, tile_first=1, tile_stride=2)
+    frame = torch.full((32, 32, 4), -7.0, dtype=torch.float32, device=dev.device)
+    rc = _abi.lib().rtamd_render_noalloc(dev._handle, C.byref(p), frame.data_ptr(), None)
+    assert rc == 0, _abi.lib().rtamd_last_error()
+    torch.cuda.synchronize()
+    assert float(frame.min()) == -7.0 and float(frame.max()) == -7.0
+    dev.render(p, frame=frame)
+    assert float(frame.min()) == -7.0 and float(frame.max()) == -7.0
+    dev.close()
