@@ -151,7 +151,13 @@ def render_and_compare(render, monkeypatch, blob, expect_on_device, label):
     assert (hd["triangle"] >= 0).mean() > 0.15
     # the checker on a window around the mesh
     w, h = blob.width, blob.height
-    win = (w // 2 - 12, h // 2 - 8, w // 2 + 12, h // 2 + 8)
+    # ... where the mesh covers most of a 24 x 16 window
+    mask = (hd["triangle"].reshape(h, w, blob.spp)[:, :, 0] >= 0).astype(np.int64)
+    ii = np.zeros((h + 1, w + 1), np.int64)
+    ii[1:, 1:] = mask.cumsum(0).cumsum(1)
+    cover = ii[16:, 24:] - ii[:-16, 24:] - ii[16:, :-24] + ii[:-16, :-24]
+    y0, x0 = np.unravel_index(int(cover.argmax()), cover.shape)
+    win = (int(x0), int(y0), int(x0) + 24, int(y0) + 16)
     colour, ohits, _ = oracle_lib.OracleScene(blob).render(rng_mode=_abi.RNG_KEYED, window=win, want_hits=True, threads=8)
     _, whits, _ = dev.render(render.make_params(rng_mode=_abi.RNG_KEYED, window=win), want_hits=True)
     assert_hits_equal(whits, ohits)
