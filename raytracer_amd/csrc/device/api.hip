@@ -67,7 +67,7 @@ struct rtamd_scene {
 	unsigned *d_qcount = nullptr;
 	DevCounters *d_counters = nullptr;
 	// coherent bounce pass (see kernels.hip): per-entry scratch sized like the queues
-	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1 };
+	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0 };
 	unsigned bounce_capacity = 0;
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	int device = -1;             // the device the scene's buffers live on
@@ -189,7 +189,7 @@ static void free_bounce_work(rtamd_scene *sc)
 	for (void *p : ptrs)
 		if (p)
 			(void)hipFree(p);
-	w = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.bits, w.small_below, w.hits_per_wave };
+	w = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.bits, w.small_below, w.hits_per_wave, w.shade_packets };
 	sc->bounce_capacity = 0;
 }
 
@@ -344,6 +344,8 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		// their n x n samples side by side in 64 lanes.
 		const char *small = getenv("RTAMD_SMALL_LEVEL");
 		sc->bounce.small_below = small ? (unsigned)strtoul(small, nullptr, 0) : 262144u;
+		const char *shade = getenv("RTAMD_BOUNCE_SHADE");
+		sc->bounce.shade_packets = shade && !strcmp(shade, "packet");
 		const int m = h.shadow_samples * h.shadow_samples;
 		int per_wave = m >= 64 ? 1 : 64 / m;
 		sc->bounce.hits_per_wave = (unsigned)(per_wave > 8 ? 8 : per_wave);
@@ -1237,6 +1239,7 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	w.bounce.bits = bits;
 	w.bounce.small_below = sc->bounce.small_below;
 	w.bounce.hits_per_wave = sc->bounce.hits_per_wave;
+	w.bounce.shade_packets = sc->bounce.shade_packets;
 	if (sorted) {
 		w.bounce.hist = reinterpret_cast<unsigned *>(base + off);
 		off = align_up(off + n_bins * sizeof(unsigned), 256);

@@ -30,6 +30,7 @@ struct BounceWork {
 	int bits;
 	unsigned small_below;    /* levels of fewer hits are shaded with their samples across lanes; 0 = never */
 	unsigned hits_per_wave;  /* ... this many hits to a wave */
+	int shade_packets;       /* sorted hits are shaded with wave-wide shafts and packets instead of per-lane walks */
 };
 hipError_t rt_launch_bounce(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
 		unsigned *queue_out_count, DevCounters *counters, unsigned grid_blocks, hipStream_t stream);

@@ -118,7 +118,7 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		sample_offsets(sc, rng_mode, glibc_table, seed, px, py, k, key, offx, offy);
 		ray = camera_ray(sc, px, py, offx, offy);
 	}
-	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_LISTS * RT_SHAFT_CAP];
+	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_POOL];
 	ShadeIO io = { &sc, rng_mode, queue_out, queue_count, queue_capacity, counters, s_shaft[wave], nullptr, nullptr };
 	rtamd_hit_record *rec = nullptr;
 	if (hits && active) {
@@ -231,7 +231,7 @@ k_bounce(DevScene sc, QueueSlice in, unsigned queue_capacity,
 	// consecutive queue entries come from the lanes of one spawning wave (one
 	// pixel's samples): they are coherent enough to walk the BVH as a packet
 	__shared__ int4 s_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
-	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_LISTS * RT_SHAFT_CAP];
+	__shared__ ShaftEntry s_shaft[RT_BLOCK / 64][RT_SHAFT_POOL];
 	int *stack = reinterpret_cast<int *>(s_stack + (threadIdx.x >> 6) * RT_MAX_STACK);
 	ShaftEntry *shaft_lists = s_shaft[threadIdx.x >> 6];
 #else
@@ -590,14 +590,17 @@ __global__ void k_bounce_scatter(QueueSlice in, const BounceBin *bbin, const uns
 // 552 ms for the unsorted pass.
 // It takes a level only when the level holds at least `min_hits` hits; smaller
 // levels go to k_bounce_shade_small.
+template <bool PACKET>
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
 k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, unsigned min_hits,
 		const BounceHit *bhit, const unsigned *perm, unsigned queue_capacity, long long *accum, QueueItem *queue_out,
 		unsigned *queue_out_count, DevCounters *counters, unsigned *cursor)
 {
 	__shared__ unsigned s_base;
-	__shared__ int s_stack[RT_MAX_STACK * RT_BLOCK];
-	int *stack = s_stack + threadIdx.x;
+	// per-lane walks: a stack per lane; packets: a stack and a pool of shaft leaves per wave
+	__shared__ int s_stack[PACKET ? (RT_BLOCK / 64) * RT_MAX_STACK * 4 : RT_MAX_STACK * RT_BLOCK];
+	__shared__ ShaftEntry s_shaft[PACKET ? RT_BLOCK / 64 : 1][PACKET ? RT_SHAFT_POOL : 1];
+	int *stack = PACKET ? s_stack + (threadIdx.x >> 6) * RT_MAX_STACK * 4 : s_stack + threadIdx.x;
 #ifdef RT_TIMING
 	if ((threadIdx.x & 63) < TM_COUNT)
 		s_timing[threadIdx.x >> 6][threadIdx.x & 63] = 0;
@@ -608,7 +611,8 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, u
 		count = queue_capacity;
 	if (count < min_hits)
 		return;
-	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters, nullptr, nullptr, nullptr };
+	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters,
+		PACKET ? s_shaft[threadIdx.x >> 6] : nullptr, nullptr, nullptr };
 	unsigned n_shadow = 0;
 	// Hit points differ widely in what their shadow rays cost (open floor against the
 	// inside of a mesh): workgroups fetch batches of RT_BLOCK hits from a shared cursor
@@ -656,7 +660,7 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, u
 			const double *dq = queue_in[q].d;
 			return d3{ dq[0], dq[1], dq[2] };
 		};
-		const c3 total = shade_hit<false, false>(io, active, surface, position, normal, ray_d, depth, key, weight, slot,
+		const c3 total = shade_hit<PACKET, false>(io, active, surface, position, normal, ray_d, depth, key, weight, slot,
 				stack, n_shadow, ray_again);
 		accumulate_runs(accum, slot, cmul(weight, total), active);
 	}
@@ -1063,8 +1067,14 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, lon
 	const unsigned small_below = work.small_below;
 	const unsigned *n_hits = work.hist + (n_bins - 1);
 	const QueueItem *items = in.items + in.first;
-	hipLaunchKernelGGL(k_bounce_shade, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits, small_below,
-			work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters, work.bounds + 6);
+	if (work.shade_packets)
+		hipLaunchKernelGGL(k_bounce_shade<true>, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
+				small_below, work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters,
+				work.bounds + 6);
+	else
+		hipLaunchKernelGGL(k_bounce_shade<false>, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
+				small_below, work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters,
+				work.bounds + 6);
 	if (small_below) {
 		const unsigned per_wave = work.hits_per_wave;
 		unsigned blocks = (small_below / per_wave + RT_BLOCK / 64 - 1) / (RT_BLOCK / 64);

@@ -9,9 +9,10 @@
 #ifndef RT_SHAFT
 #define RT_SHAFT 1
 #endif
-#ifndef RT_SHAFT_CAP
-#define RT_SHAFT_CAP 24        // leaves per list; a fuller shaft falls back to the BVH walk
+#ifndef RT_SHAFT_POOL
+#define RT_SHAFT_POOL 96       // leaves a wave's lists hold together (at most 254); a shaft that needs more falls back to the BVH walk
 #endif
+#define RT_SHAFT_CAP RT_SHAFT_POOL
 #ifndef RT_SHAFT_LISTS
 #define RT_SHAFT_LISTS 4       // mesh surfaces (in traversal order) that get a list
 #endif

@@ -127,8 +127,8 @@ DEV void shaft_to_model(CSurface &s, f3 c, f3 r, f3 &cm, f3 &rm)
 
 // Collects the leaves of a mesh whose box the shaft touches.  Everything here
 // is wave-uniform.  Returns the number of leaves, or -1 when there are more than
-// RT_SHAFT_CAP (or the mesh is a single leaf): the caller then walks the BVH.
-DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int *wstack_i, ShaftEntry *out)
+// `cap` (or the mesh is a single leaf): the caller then walks the BVH.
+DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int *wstack_i, ShaftEntry *out, int cap)
 {
 	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
 	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
@@ -148,7 +148,7 @@ DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int 
 		bool have_next = false;
 		if (h0) {
 			if (c0 < 0) {
-				if (n == RT_SHAFT_CAP)
+				if (n == cap)
 					return -1;
 				if (writer)
 					out[n] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, c0, 0 };
@@ -160,7 +160,7 @@ DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int 
 		}
 		if (h1) {
 			if (c1 < 0) {
-				if (n == RT_SHAFT_CAP)
+				if (n == cap)
 					return -1;
 				if (writer)
 					out[n] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c1, 0 };
@@ -261,7 +261,8 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 		0.5f * (lhi.y - llo.y) + pad1 + k * (__builtin_fabsf(llo.y) + __builtin_fabsf(lhi.y)),
 		0.5f * (lhi.z - llo.z) + pad1 + k * (__builtin_fabsf(llo.z) + __builtin_fabsf(lhi.z)) };
 	const ShaftTest world = shaft_make(c0, r0, c1, r1);
-	int slot = 0;
+	// the lists of a wave share one pool of entries: a list starts where the one before it ends
+	int slot = 0, used = 0;
 	for (int si = 0; si < sc.num_surfaces; si++) {
 		CSurface &s = in_const(sc.surfaces)[si];
 		const bool is_mesh = s.shape_type == RTAMD_SHAPE_MESH;
@@ -285,9 +286,11 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 		shaft_to_model(s, c0, r0, cm0, rm0);
 		shaft_to_model(s, c1, r1, cm1, rm1);
 		const ShaftTest model = shaft_make(cm0, rm0, cm1, rm1);
-		const int n_leaves = shaft_collect(sc, in_const(sc.meshes)[s.mesh], model, wstack, lists + my_slot * RT_SHAFT_CAP);
+		const int room = RT_SHAFT_POOL - used < 254 ? RT_SHAFT_POOL - used : 254;
+		const int n_leaves = shaft_collect(sc, in_const(sc.meshes)[s.mesh], model, wstack, lists + used, room);
 		RT_STAT(if (counter) atomicAdd(&g_stat_shaft[n_leaves >= 0 ? n_leaves : RT_SHAFT_CAP + 1], 1ull));
 		if (n_leaves >= 0) {
+			used += n_leaves;
 			ss.counts = (ss.counts & ~(0xffu << (8 * my_slot))) | ((unsigned)n_leaves << (8 * my_slot));
 			ss.surfaces = (ss.surfaces & ~(0xffu << (8 * my_slot))) | ((unsigned)si << (8 * my_slot));
 		}

@@ -36,13 +36,19 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 	const SlabRay slab = slab_ray(ray);
 	for (int si = next_wanted(0); si < sc.num_surfaces; si = next_wanted(si + 1)) {
 		CSurface &s = in_const(sc.surfaces)[si];
-		int shaft_count = 0xff, shaft_slot = 0;
+		int shaft_count = 0xff, shaft_first = 0;
 		if (masked) {
-			for (int k = 0; k < RT_SHAFT_LISTS; k++)
+			// the lists lie one after the other in the wave's pool
+			int first = 0;
+			for (int k = 0; k < RT_SHAFT_LISTS; k++) {
+				const int cnt = (int)((shaft.counts >> (8 * k)) & 0xffu);
 				if ((int)((shaft.surfaces >> (8 * k)) & 0xffu) == si) {
-					shaft_count = (int)((shaft.counts >> (8 * k)) & 0xffu);
-					shaft_slot = k;
+					shaft_count = cnt;
+					shaft_first = first;
 				}
+				if (cnt != 0xff)
+					first += cnt;
+			}
 		}
 		RT_EV(ANYHIT ? EV_BBOX_SHADOW : EV_BBOX_PRIMARY);
 		float bnear, bfar;
@@ -76,7 +82,7 @@ DEV bool trace(const DevScene &sc, const Ray &ray, int *stack, Best &best, const
 				RT_EV(EV_MESH_LIST_SHADOW);
 				// every listed leaf's triangles; a hit's t lies in [bnear, bfar]
 				hits = mesh_candidates_anyhit(sc, in_const(sc.meshes)[s.mesh], o, d, bnear, bfar,
-						shaft.lists + shaft_slot * RT_SHAFT_CAP, shaft_count) ? 1 : 0;
+						shaft.lists + shaft_first, shaft_count) ? 1 : 0;
 				t = (double)bnear;
 			} else if (PACKET) {
 				RT_EV(ANYHIT ? EV_MESH_WALK_SHADOW : EV_MESH_WALK_PRIMARY);
