@@ -81,6 +81,20 @@ def cpu_baseline(blob):
                 f"{port['rays']} rays")
         out = {"value": port["mrays_per_s"], "unit": "Mrays/s", "cores": 1, "kind": "port",
                "sample": desc}
+        # the restatement on all host cores this job may use (rows of a 2x larger sample
+        # dealt out over threads, keyed samples: the serial stream cannot be split)
+        cores = max(1, min(16, os.cpu_count() or 1))
+        big = os.path.join(tmp, "sample2.blob")
+        blob.with_config(width=2 * w, height=2 * h).save(big)
+        try:
+            allc = json.loads(subprocess.run([cli, "render", big, os.path.join(tmp, "a"), "--rng", "keyed",
+                                              "--threads", str(cores)], check=True, capture_output=True,
+                                             text=True, timeout=600).stdout)
+            all_cores = {"value": allc["mrays_per_s"], "unit": "Mrays/s", "cores": cores,
+                         "sample": f"{2 * w}x{2 * h}, 64 spp, keyed samples, {allc['rays']} rays"}
+        except Exception:
+            all_cores = None
+        out["port_all_cores"] = all_cores
         if os.path.exists(ref):
             try:
                 txt = subprocess.run([ref, "render", bpath, os.path.join(tmp, "r"), "--no-ppm"],
@@ -89,7 +103,7 @@ def cpu_baseline(blob):
                 out = {"value": port["rays"] / secs / 1e6, "unit": "Mrays/s", "cores": 1,
                        "kind": "reference", "sample": desc + "; reference sources compiled -O2 IEEE, "
                        "kd-tree counters zero-initialised by the compiler flag",
-                       "port_value": port["mrays_per_s"]}
+                       "port_value": port["mrays_per_s"], "port_all_cores": all_cores}
             except Exception:
                 pass
     return out, port
@@ -108,6 +122,17 @@ def measured_counters(scene):
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def secondary_record():
+    """The second hot kernel, measured on the GPU box at its own configuration
+    (8-glossy 640x640 at 64 samples per pixel: the bounce pass) and committed with its
+    counter passes; None when the record is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "secondary_8-glossy.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def free_port():
@@ -211,21 +236,26 @@ def main():
         dist.all_reduce(counts)
     rays_frame = int(counts[0].item())
 
+    # Timed region: frames without statistics, so no rank waits for its device before the
+    # gather.  Every primary-kernel launch is bracketed by HIP events on the launch stream
+    # inside the library (RTAMD_RENDER_TIME_KERNELS); they are read after the region.
+    timed = render.make_params(rng_mode=_abi.RNG_KEYED, tile=(32, 32), flags=_abi.RENDER_TIME_KERNELS)
+    scene.take_kernel_times()
     barrier()
-    kernel_ms_sum, kernel_launches = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        # the library brackets its primary-kernel launches with HIP events on the
-        # launch stream; reading them back costs one stream sync per frame
-        _, sti = step(want_stats=True)
-        kernel_ms_sum += sti.ms_primary
-        kernel_launches += sti.launches_primary
+        rdist.render_frame(scene, timed, rank, world, frame=frame, want_stats=False, gather=gather)
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms_sum, kernel_launches = scene.take_kernel_times()
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    ok = torch.tensor([1.0], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # every rank has rendered and gathered all its frames when it gets here
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     elapsed = float(t.item())
+    ranks_ok = bool(ok.item() == 1.0)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -234,7 +264,7 @@ def main():
             "metric": "Mrays/s (primary+secondary)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ranks_ok": ranks_ok,
             "config": {"workload": f"{args.scene}.sdl {blob.width}x{blob.height} {blob.spp} spp, "
                                    "keyed samples, 32x32 tiles dealt cyclically over ranks, "
                                    "framebuffer gather to rank 0",
@@ -266,7 +296,12 @@ def main():
                 "frac_vs_fp32_peak": achieved / (2 * PEAK_FP64_VECTOR_TFLOPS),
                 "valu_busy": pmc["valu_busy"], "valu_insts_per_ray": pmc["valu_insts_per_ray"],
                 "fp64_inst_share": pmc["fp64_inst_share"], "lane_utilisation": pmc["lane_utilisation"],
-                "salu_per_valu": pmc["salu_per_valu"], "counters_kernel_ms": pmc["kernel_ms"]})
+                "salu_per_valu": pmc["salu_per_valu"], "counters_kernel_ms": pmc["kernel_ms"],
+                # what the counter passes say about the memory side and the occupancy: hit rate of
+                # the L2 (BVH nodes, triangles and scene tables are all served from it), HBM
+                # bandwidth actually moved, waves resident per SIMD
+                "l2_hit_rate": pmc.get("l2_hit_rate"), "hbm_gbps": pmc.get("hbm_gbps"),
+                "waves_per_simd": pmc.get("waves_per_simd")})
         if port:
             # the survey's implementation-independent model of the REFERENCE's work for these
             # rays (not executed flops): kept for comparison with the survey's roof
@@ -276,6 +311,9 @@ def main():
                          "nominal_reference_tflops": nominal,
                          "nominal_frac_of_fp64_peak": nominal / PEAK_FP64_VECTOR_TFLOPS})
         result["roofline"] = roof
+        sec = secondary_record()
+        if sec:
+            result["secondary"] = sec
         if cpu:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -225,9 +225,14 @@ typedef struct rtamd_render_params {
 	/* Optional pixel window [x0,x1) x [y0,y1) inside the frame (all zero =
 	 * whole frame); pixels outside it are left untouched. */
 	int32_t x0, y0, x1, y1;
-	int32_t flags;                  /* reserved, 0 */
+	int32_t flags;                  /* RTAMD_RENDER_* bits, 0 = none */
 	int32_t pad;
 } rtamd_render_params;
+
+/* rtamd_render without `stats`: bracket every primary-kernel launch with HIP events on
+ * the launch stream and keep them with the scene; rtamd_scene_take_kernel_times reads
+ * them later.  The call stays asynchronous (no wait for the device per frame). */
+#define RTAMD_RENDER_TIME_KERNELS 1
 
 typedef struct rtamd_render_stats {
 	uint64_t rays_primary;          /* ray_intersect-equivalent queries, by kind */
@@ -306,7 +311,19 @@ int rtamd_tiles_pack(int width, int height, const rtamd_render_params *params,
 int rtamd_tiles_unpack(int width, int height, const rtamd_render_params *params,
 		const void *d_packed, void *d_frame, void *stream);
 
+/* rtamd_tiles_unpack for the owners first_owner .. tile_stride-1 in ONE launch: owner
+ * r's dense buffer starts at d_packed_all + r * owner_stride_bytes (the layout a gather
+ * of equal-size per-rank buffers leaves on rank 0; params->tile_first is ignored).
+ * Has no counterpart in the reference (its frame is written by one loop, raytracer.c:78-84). */
+int rtamd_tiles_unpack_all(int width, int height, const rtamd_render_params *params, int first_owner,
+		const void *d_packed_all, uint64_t owner_stride_bytes, void *d_frame, void *stream);
+
 /* Host-side query helpers. */
+/* Device time of the primary-kernel launches recorded since the last call by renders
+ * with RTAMD_RENDER_TIME_KERNELS (waits for the last of them): their sum in ms and
+ * their number.  The measurement behind the reference's "Rendering took ..." line
+ * (raytracer.c:76,89-90), taken per kernel launch. */
+int rtamd_scene_take_kernel_times(rtamd_scene *scene, float *ms_primary, int *launches);
 /* Seconds rtamd_scene_create spent on mesh `mesh`'s acceleration structure (the
  * figure behind the reference's "Building kd-tree took ..." line, scene.c:663-666). */
 int rtamd_scene_mesh_build_seconds(const rtamd_scene *scene, int mesh, double *seconds);

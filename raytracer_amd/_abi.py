@@ -18,6 +18,7 @@ RTAMD_MAX_LIGHTS = 8
 SHAPE_PLANE, SHAPE_DISK, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_CONE, SHAPE_MESH = range(6)
 LIGHT_POINT, LIGHT_AREA = 0, 1
 RNG_GLIBC, RNG_KEYED = 0, 1
+RENDER_TIME_KERNELS = 1     # rtamd_render_params.flags
 
 STATUS_NAMES = {
     0: "RTAMD_OK", -1: "RTAMD_ERR_ARG", -2: "RTAMD_ERR_IO", -3: "RTAMD_ERR_SCENE",
@@ -124,6 +125,9 @@ PROTOTYPES = {
                                    C.c_void_p, C.c_void_p]),
     "rtamd_tiles_unpack": (C.c_int, [C.c_int, C.c_int, C.POINTER(RenderParams), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "rtamd_tiles_unpack_all": (C.c_int, [C.c_int, C.c_int, C.POINTER(RenderParams), C.c_int, C.c_void_p,
+                                         C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rtamd_scene_take_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "rtamd_last_cubemap_load_seconds": (C.c_double, []),
     "rtamd_scene_mesh_build_seconds": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "rtamd_scene_mesh_built_on_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

@@ -149,6 +149,22 @@ int main(int argc, char **argv)
 
 	rtamd_render_params p;
 	memset(&p, 0, sizeof p);
+	/* tile exchange buffers of a multi-device run, allocated before the clock starts: a
+	 * dense block of owner 0's size (the largest) per device, and their landing place on
+	 * the first device */
+	void *packed[MAX_DEVICES] = { NULL }, *landing = NULL;
+	size_t pbytes = 0;
+	if (ndev > 1) {
+		p.tile_w = p.tile_h = TILE;
+		p.tile_stride = ndev;
+		pbytes = (size_t)rtamd_tiles_owned(w, hh, &p) * TILE * TILE * 4 * sizeof(float);
+		if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&landing, pbytes * ndev) != hipSuccess)
+			return fail("Could not allocate the tile exchange buffer");
+		for (int k = 1; k < ndev; k++)
+			if (hipSetDevice(devices[k]) != hipSuccess || hipMalloc(&packed[k], pbytes) != hipSuccess ||
+					hipMemset(packed[k], 0, pbytes) != hipSuccess)
+				return fail("Could not allocate the tile exchange buffer");
+	}
 	p.seed = seed;
 	p.rng_mode = rng >= 0 ? rng : RTAMD_RNG_GLIBC;
 	p.tile_w = p.tile_h = TILE;
@@ -184,33 +200,31 @@ int main(int argc, char **argv)
 				return fail("A device failed while rendering");
 		print_progressbar(y1 - 1, hh - 1);        /* raytracer.c:83 */
 	}
-	/* the other devices' tiles: packed there, copied peer to peer, unpacked into device 0's frame */
+	/* the other devices' tiles: packed there, copied peer to peer into device 0's landing
+	 * buffer (one block per device) by asynchronous copies that run side by side, then
+	 * unpacked into device 0's frame by one launch */
 	if (ndev > 1) {
 		p.x0 = p.y0 = p.x1 = p.y1 = 0;
-		p.tile_first = 0;
-		const int most = rtamd_tiles_owned(w, hh, &p);
-		const size_t pbytes = (size_t)most * TILE * TILE * 4 * sizeof(float);
-		void *landing = NULL;
-		if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&landing, pbytes) != hipSuccess)
-			return fail("Could not allocate the tile exchange buffer");
 		for (int k = 1; k < ndev; k++) {
-			void *packed = NULL;
 			p.tile_first = k;
-			if (hipSetDevice(devices[k]) != hipSuccess || hipMalloc(&packed, pbytes) != hipSuccess ||
-					hipMemset(packed, 0, pbytes) != hipSuccess)
-				return fail("Could not allocate the tile exchange buffer");
-			if (rtamd_tiles_pack(w, hh, &p, d_colour[k], packed, NULL))
+			if (hipSetDevice(devices[k]) != hipSuccess)
+				return fail("Could not select a device");
+			if (rtamd_tiles_pack(w, hh, &p, d_colour[k], packed[k], NULL))
 				return fail(rtamd_last_error());
-			if (hipDeviceSynchronize() != hipSuccess ||
-					hipMemcpyPeer(landing, devices[0], packed, devices[k], pbytes) != hipSuccess)
+			/* on device k's null stream, behind the pack kernel */
+			if (hipMemcpyPeerAsync((char *)landing + (size_t)k * pbytes, devices[0], packed[k], devices[k], pbytes,
+					NULL) != hipSuccess)
 				return fail("Peer copy of the rendered tiles failed");
-			(void)hipFree(packed);
-			if (hipSetDevice(devices[0]) != hipSuccess || rtamd_tiles_unpack(w, hh, &p, landing, d_colour[0], NULL))
-				return fail(rtamd_last_error());
-			if (hipDeviceSynchronize() != hipSuccess)
-				return fail("Unpacking the rendered tiles failed");
 		}
-		(void)hipFree(landing);
+		for (int k = 1; k < ndev; k++)
+			if (hipSetDevice(devices[k]) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+				return fail("Peer copy of the rendered tiles failed");
+		p.tile_first = 0;
+		if (hipSetDevice(devices[0]) != hipSuccess ||
+				rtamd_tiles_unpack_all(w, hh, &p, 1, landing, pbytes, d_colour[0], NULL))
+			return fail(rtamd_last_error());
+		if (hipDeviceSynchronize() != hipSuccess)
+			return fail("Unpacking the rendered tiles failed");
 	}
 	const double seconds = now() - t0;
 	printf("\n");                                 /* raytracer.c:85 */
@@ -233,6 +247,10 @@ int main(int argc, char **argv)
 	for (int k = 0; k < ndev; k++) {
 		(void)hipSetDevice(devices[k]);
 		(void)hipFree(d_colour[k]);
+		if (packed[k])
+			(void)hipFree(packed[k]);
+		if (k == 0 && landing)
+			(void)hipFree(landing);
 		rtamd_scene_destroy(scene[k]);
 	}
 	rtamd_blob_free(blob);

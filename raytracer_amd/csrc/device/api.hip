@@ -72,6 +72,8 @@ struct rtamd_scene {
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	int device = -1;             // the device the scene's buffers live on
 	std::vector<double> mesh_build_seconds;
+	// RTAMD_RENDER_TIME_KERNELS: event pairs around primary launches, read by rtamd_scene_take_kernel_times
+	std::vector<hipEvent_t> deferred_events;
 	std::vector<char> mesh_built_on_device;   // per mesh: its tree is the GPU-built one
 	unsigned queue_capacity_max = 0;
 	unsigned overflow_test_capacity = 0;
@@ -201,6 +203,8 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 		(void)hipSetDevice(sc->device);
 	for (void *p : sc->allocations)
 		(void)hipFree(p);
+	for (hipEvent_t e : sc->deferred_events)
+		(void)hipEventDestroy(e);
 	if (sc->d_glibc) (void)hipFree(sc->d_glibc);
 	if (sc->d_glibc_powers) (void)hipFree(sc->d_glibc_powers);
 	if (sc->d_glibc_window) (void)hipFree(sc->d_glibc_window);
@@ -942,19 +946,23 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 			if (levels)
 				HIP_TRY(hipMemsetAsync(w.qcount, 0, sizeof(unsigned) * 128, stream));
 			const bool timed = stats && ev.chunks.size() < 2 * MAX_TIMED_CHUNKS;
-			if (timed) {
+			// without statistics: the event pairs stay with the scene and are read later,
+			// so the call itself never waits for the device
+			const bool deferred = !stats && (p.flags & RTAMD_RENDER_TIME_KERNELS) &&
+					sc->deferred_events.size() < 2 * MAX_TIMED_CHUNKS;
+			if (timed || deferred) {
 				hipEvent_t e = nullptr;
 				HIP_TRY(hipEventCreate(&e));
-				ev.chunks.push_back(e);
+				(timed ? ev.chunks : sc->deferred_events).push_back(e);
 				HIP_TRY(hipEventRecord(e, stream));
 			}
 			HIP_TRY(rt_launch_primary(dev, p, first, count, table, accum,
 					direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits),
 					levels ? w.queue[0] : nullptr, levels ? w.qcount : nullptr, kernel_capacity, w.counters, stream));
-			if (timed) {
+			if (timed || deferred) {
 				hipEvent_t e = nullptr;
 				HIP_TRY(hipEventCreate(&e));
-				ev.chunks.push_back(e);
+				(timed ? ev.chunks : sc->deferred_events).push_back(e);
 				HIP_TRY(hipEventRecord(e, stream));
 			}
 			launches_primary++;
@@ -1429,4 +1437,56 @@ extern "C" int rtamd_tiles_unpack(int width, int height, const rtamd_render_para
 	HIP_TRY(rt_launch_tiles_copy(width, height, p, static_cast<float *>(d_frame),
 			static_cast<float *>(const_cast<void *>(d_packed)), 1, static_cast<hipStream_t>(stream_v)));
 	return 0;
+}
+
+extern "C" int rtamd_tiles_unpack_all(int width, int height, const rtamd_render_params *params, int first_owner,
+		const void *d_packed_all, uint64_t owner_stride_bytes, void *d_frame, void *stream_v)
+{
+	rtamd_render_params p;
+	int rc = normalise_params(width, height, params, &p);
+	if (rc)
+		return rc;
+	if (!d_frame || !d_packed_all || first_owner < 0 || first_owner > p.tile_stride || owner_stride_bytes % 16) {
+		rtamd_set_error("rtamd_tiles_unpack_all: bad argument");
+		return RTAMD_ERR_ARG;
+	}
+	p.tile_first = 0;
+	const uint64_t need = (uint64_t)rt_tiles_owned(width, height, p) * (unsigned)(p.tile_w * p.tile_h) * 16;
+	if (owner_stride_bytes < need) {
+		rtamd_set_error("rtamd_tiles_unpack_all: owner stride of %llu bytes is less than the %llu bytes owner 0's "
+				"tiles take", (unsigned long long)owner_stride_bytes, (unsigned long long)need);
+		return RTAMD_ERR_ARG;
+	}
+	HIP_TRY(rt_launch_tiles_unpack_all(width, height, p, first_owner, static_cast<float *>(d_frame),
+			static_cast<const float *>(d_packed_all), owner_stride_bytes / 16, static_cast<hipStream_t>(stream_v)));
+	return 0;
+}
+
+extern "C" int rtamd_scene_take_kernel_times(rtamd_scene *sc, float *ms_primary, int *launches)
+{
+	if (!sc || !ms_primary || !launches) {
+		rtamd_set_error("rtamd_scene_take_kernel_times: NULL argument");
+		return RTAMD_ERR_ARG;
+	}
+	*ms_primary = 0.0f;
+	*launches = 0;
+	if (int rc0 = use_scene_device(sc))
+		return rc0;
+	int rc = 0;
+	for (size_t i = 0; i + 1 < sc->deferred_events.size(); i += 2) {
+		float ms = 0.0f;
+		hipError_t e = hipEventSynchronize(sc->deferred_events[i + 1]);
+		if (e == hipSuccess)
+			e = hipEventElapsedTime(&ms, sc->deferred_events[i], sc->deferred_events[i + 1]);
+		if (e != hipSuccess && !rc) {
+			rtamd_set_error("rtamd_scene_take_kernel_times: %s", hipGetErrorString(e));
+			rc = RTAMD_ERR_HIP;
+		}
+		*ms_primary += ms;
+		*launches += 1;
+	}
+	for (hipEvent_t e : sc->deferred_events)
+		(void)hipEventDestroy(e);
+	sc->deferred_events.clear();
+	return rc;
 }

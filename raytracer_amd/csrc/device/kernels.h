@@ -47,5 +47,7 @@ hipError_t rt_launch_camera_rays(const DevScene &sc, const rtamd_render_params &
 		GlibcTable glibc_table, double *rays, hipStream_t stream);
 hipError_t rt_launch_tiles_copy(int width, int height, const rtamd_render_params &p, float *frame,
 		float *packed, int unpack, hipStream_t stream);
+hipError_t rt_launch_tiles_unpack_all(int width, int height, const rtamd_render_params &p, int first_owner,
+		float *frame, const float *packed_all, unsigned long long owner_stride_float4, hipStream_t stream);
 
 #endif

@@ -955,6 +955,28 @@ __global__ void k_tiles_copy(int width, int height, TileMap tm, float *frame, fl
 		*p = *f;
 }
 
+// The tiles of several owners in one launch (rank 0 after the framebuffer gather):
+// blockIdx.y selects the owner, whose dense buffer starts owner_stride float4 after
+// the previous owner's.
+__global__ void k_tiles_unpack_all(int width, int height, TileMap tm, int first_owner, float *frame,
+		const float *packed_all, unsigned long long owner_stride)
+{
+	const int owner = first_owner + (int)blockIdx.y;
+	const int total = tm.tiles_x * tm.tiles_y;
+	tm.tile_first = owner;
+	tm.owned = owner < total ? (total - owner + tm.tile_stride - 1) / tm.tile_stride : 0;
+	tm.x0 = 0; tm.y0 = 0; tm.x1 = width; tm.y1 = height;
+	unsigned long long pix = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (pix >= (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h))
+		return;
+	int px, py, k;
+	uint32_t slot;
+	if (!sample_to_pixel(tm, 1, pix, px, py, k, slot))
+		return;
+	const float4 *p = reinterpret_cast<const float4 *>(packed_all) + owner_stride * (unsigned long long)owner + pix;
+	reinterpret_cast<float4 *>(frame)[(unsigned long long)width * py + px] = *p;
+}
+
 // =============================================================================
 // Host-side launchers (called from api.hip)
 // =============================================================================
@@ -1139,5 +1161,22 @@ hipError_t rt_launch_tiles_copy(int width, int height, const rtamd_render_params
 	unsigned long long blocks = (pixels + 255) / 256;
 	hipLaunchKernelGGL(k_tiles_copy, dim3((unsigned)blocks), dim3(256), 0, stream, width, height, tm, frame,
 			packed, unpack);
+	return hipGetLastError();
+}
+
+hipError_t rt_launch_tiles_unpack_all(int width, int height, const rtamd_render_params &p, int first_owner,
+		float *frame, const float *packed_all, unsigned long long owner_stride_float4, hipStream_t stream)
+{
+	rtamd_render_params q = p;
+	q.tile_first = 0;
+	TileMap tm = make_tile_map(width, height, q);
+	// owner 0 holds the most tiles
+	unsigned long long pixels = (unsigned long long)tm.owned * (unsigned)(tm.tile_w * tm.tile_h);
+	const int owners = p.tile_stride - first_owner;
+	if (!pixels || owners <= 0)
+		return hipSuccess;
+	unsigned long long blocks = (pixels + 255) / 256;
+	hipLaunchKernelGGL(k_tiles_unpack_all, dim3((unsigned)blocks, (unsigned)owners), dim3(256), 0, stream, width, height,
+			tm, first_owner, frame, packed_all, owner_stride_float4);
 	return hipGetLastError();
 }

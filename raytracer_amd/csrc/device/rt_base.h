@@ -51,9 +51,12 @@ __device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
 // wave-level event counts: see the EV_ names
 __device__ unsigned long long g_stat_ev[32];
 enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
-	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS, EV_CULLED,
+	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS,
+	// per-lane walks: walks started (per wave) and the lanes in them, loop iterations and the lanes in them
+	EV_LANE_WALKS, EV_LANE_WALK_LANES, EV_LANE_STEPS, EV_LANE_STEP_LANES,
 	EV_BOX_SIZE0 = 16 /* .. 31: largest extent of a wave's hit-point box, 0.001 * 2^k */ };
-#define RT_EV(e) do { if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], 1ull); } while (0)
+#define RT_EV_ADD(e, n) do { const unsigned long long n_ = (unsigned long long)(n); if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], n_); } while (0)
+#define RT_EV(e) RT_EV_ADD(e, 1)
 #else
 #define RT_EV(e) do { } while (0)
 #endif

@@ -158,7 +158,9 @@ DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear,
 	float limit = tfar;          // float upper bound of the search window, >= best_t
 	int sp = 0;
 	int ref = mesh.root;
+	RT_STAT(if (ANYHIT) { RT_EV_ADD(EV_LANE_WALKS, 1); RT_EV_ADD(EV_LANE_WALK_LANES, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true))); });
 	for (;;) {
+		RT_STAT(if (ANYHIT) { RT_EV_ADD(EV_LANE_STEPS, 1); RT_EV_ADD(EV_LANE_STEP_LANES, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true))); });
 		if (ref >= 0) {
 			RT_STAT(atomicAdd(&g_stat_nodes, 1ull));
 			const float4 q0 = nodes[4 * ref + 0], q1 = nodes[4 * ref + 1];

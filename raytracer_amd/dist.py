@@ -37,13 +37,19 @@ class FrameGather:
         self.packed = torch.zeros(shape, dtype=torch.float32, device=frame.device)
         self.send = torch.zeros(shape, dtype=torch.float32, pin_memory=True) if self.staged else self.packed
         self.recv = None
+        self.recv_all = None
         self.recv_dev = None
         if rank == 0 and world > 1:
+            # ONE buffer for all ranks (the gather's outputs are views of it), so that the
+            # tiles of every other rank are unpacked by a single launch
             where = "cpu" if self.staged else frame.device
-            self.recv = [torch.zeros(shape, dtype=torch.float32, device=where) for _ in range(world)]
+            self.recv_all = torch.zeros((world,) + shape, dtype=torch.float32, device=where,
+                                        pin_memory=bool(self.staged))
+            self.recv = [self.recv_all[r] for r in range(world)]
             if self.staged:
-                self.recv_dev = torch.zeros(shape, dtype=torch.float32, device=frame.device)
+                self.recv_dev = torch.zeros((world,) + shape, dtype=torch.float32, device=frame.device)
         self.owner = [owner_params(base_params, r, world) for r in range(world)]
+        self.all_params = owner_params(base_params, 0, world)
 
     def __call__(self, frame):
         """Collects every rank's tiles into rank 0's `frame` (in place); `frame` holds
@@ -63,12 +69,19 @@ class FrameGather:
             self.packed[: own.shape[0]] = torch.from_numpy(own)
         dist.gather(self.send, self.recv, dst=0, group=self.group)
         if self.rank == 0:
-            for r in range(1, self.world):
-                buf = self.recv[r]
+            if self.cuda:
+                buf = self.recv_all
                 if self.staged:
-                    self.recv_dev.copy_(buf)
+                    self.recv_dev.copy_(self.recv_all, non_blocking=True)
                     buf = self.recv_dev
-                _unpack(buf, frame, self.owner[r])
+                s = torch.cuda.current_stream(frame.device)
+                stride = buf[0].numel() * 4
+                _abi.check(_abi.lib().rtamd_tiles_unpack_all(w, h, C.byref(self.all_params), 1, buf.data_ptr(),
+                                                             stride, frame.data_ptr(), s.cuda_stream),
+                           "rtamd_tiles_unpack_all")
+            else:
+                for r in range(1, self.world):
+                    _unpack(self.recv[r], frame, self.owner[r])
         return frame
 
 

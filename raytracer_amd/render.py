@@ -28,7 +28,7 @@ def init(device=0):
 
 
 def make_params(seed=DEFAULT_SEED, rng_mode=_abi.RNG_KEYED, tile=(32, 32), tile_first=0,
-                tile_stride=1, window=None):
+                tile_stride=1, window=None, flags=0):
     p = _abi.RenderParams()
     p.seed = seed
     p.rng_mode = rng_mode
@@ -37,6 +37,7 @@ def make_params(seed=DEFAULT_SEED, rng_mode=_abi.RNG_KEYED, tile=(32, 32), tile_
     p.tile_stride = tile_stride
     if window is not None:
         p.x0, p.y0, p.x1, p.y1 = window
+    p.flags = flags
     return p
 
 
@@ -96,6 +97,14 @@ class DeviceScene:
         if hits_t is not None:
             hits = hits_from_bytes(hits_t.cpu().numpy())
         return frame, hits, stats
+
+    def take_kernel_times(self):
+        """(ms, launches) of the primary-kernel launches recorded by renders with
+        flags=_abi.RENDER_TIME_KERNELS since the last call; waits for the last one."""
+        ms, n = C.c_float(), C.c_int()
+        _abi.check(_abi.lib().rtamd_scene_take_kernel_times(self._handle, C.byref(ms), C.byref(n)),
+                   "rtamd_scene_take_kernel_times")
+        return ms.value, n.value
 
     def trace(self, rays):
         """rtamd_trace: rays float64 [n, 8] (origin, direction, near, far)."""

@@ -9,6 +9,9 @@ Derived figures (per launch of the kernel, averaged over its dispatches):
   lane_utilisation           SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)
   valu_busy                  4 SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles per XCD),
                              cycles per XCD = GRBM_GUI_ACTIVE / 8
+  l2_hit_rate                TCC_HIT / (TCC_HIT + TCC_MISS)
+  hbm_gbps                   bytes_per_launch / kernel time
+  waves_per_simd             4 SQ_WAVE_CYCLES / (1024 SIMDs x cycles per XCD)
   bytes_per_launch           HBM traffic: 2 x FETCH_SIZE + WRITE_SIZE, in KB of 1024 B
                              (gfx950 tallies 128-byte fetches at 64 bytes)
 """
@@ -54,6 +57,10 @@ rec = {
     "salu_per_valu": c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"],
     "wait_inst_share_of_wave_cycles": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
     "bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
+    "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+    "hbm_gbps": ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / (ms / launches * 1e-3) / 1e9) if ms else None,
+    # SQ_WAVE_CYCLES counts resident wave time in units of four cycles, like the other SQ cycle counters
+    "waves_per_simd": 4 * c["SQ_WAVE_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8),
     "counters": c,
     "note": "rocprofv3 --pmc, one run per pass (scripts/pmc_passes.sh), program directly after --; "
             "valu_insts_per_ray counts lane-instructions (wave instructions x 64)",
