@@ -33,7 +33,7 @@ struct BounceWork {
 	int shade_packets;       /* sorted hits are shaded with wave-wide shafts and packets instead of per-lane walks */
 };
 hipError_t rt_launch_bounce(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
-		unsigned *queue_out_count, DevCounters *counters, unsigned grid_blocks, hipStream_t stream);
+		unsigned *queue_out_count, DevCounters *counters, unsigned grid_blocks, bool packets, hipStream_t stream);
 hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
 		unsigned *queue_out_count, DevCounters *counters, const BounceWork &work, unsigned grid_blocks,
 		hipStream_t stream);

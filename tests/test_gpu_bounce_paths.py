@@ -2,9 +2,11 @@
 
 A bounce level of a scene with area lights is shaded either by k_bounce_shade
 (one lane per hit in spatial order, batches from a cursor: levels of at least
-RTAMD_SMALL_LEVEL hits, 2^18 by default), by k_bounce_shade_small (a hit's light
-samples across the lanes of a wave: smaller levels) or by k_bounce (the unsorted
-pass, RTAMD_BOUNCE=legacy; the default for scenes without area lights).  Test
+RTAMD_SMALL_LEVEL hits, 2^18 by default; shadow rays walked per lane, or as
+wave-wide packets with RTAMD_BOUNCE_SHADE=packet), by k_bounce_shade_small (a
+hit's light samples across the lanes of a wave: smaller levels) or by k_bounce
+(the unsorted pass, RTAMD_BOUNCE=legacy; the default for scenes without area
+lights; bounced rays walked per lane or as packets, RTAMD_BOUNCE_WALK).  Test
 frames are small, so without the overrides below only the second form would
 ever meet the checker.  The overrides are read when the scene is created.
 
@@ -34,12 +36,14 @@ FORMS = {
     "per-lane-sorted": {"RTAMD_BOUNCE": "sorted", "RTAMD_SMALL_LEVEL": "0"},
     "samples-across-lanes": {"RTAMD_BOUNCE": "sorted", "RTAMD_SMALL_LEVEL": "4000000000"},
     "straddle": {"RTAMD_BOUNCE": "sorted", "RTAMD_SMALL_LEVEL": "3000"},
-    "unsorted": {"RTAMD_BOUNCE": "legacy"},
+    "unsorted": {"RTAMD_BOUNCE": "legacy", "RTAMD_BOUNCE_WALK": "lane"},
+    "unsorted-packets": {"RTAMD_BOUNCE": "legacy", "RTAMD_BOUNCE_WALK": "packet"},
+    "sorted-packets": {"RTAMD_BOUNCE": "sorted", "RTAMD_SMALL_LEVEL": "0", "RTAMD_BOUNCE_SHADE": "packet"},
 }
 
 
 def scene_with(render, monkeypatch, blob, env):
-    for k in ("RTAMD_BOUNCE", "RTAMD_SMALL_LEVEL", "RTAMD_SORT_BITS"):
+    for k in ("RTAMD_BOUNCE", "RTAMD_SMALL_LEVEL", "RTAMD_SORT_BITS", "RTAMD_BOUNCE_WALK", "RTAMD_BOUNCE_SHADE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -97,14 +101,15 @@ def test_sorted_pass_on_a_scene_without_area_lights(render, monkeypatch):
     p = render.make_params(rng_mode=_abi.RNG_KEYED)
     want = checker("small_4-environmentmap", blob)
     frames = []
-    for form in ("per-lane-sorted", "samples-across-lanes", "default"):
+    for form in ("per-lane-sorted", "samples-across-lanes", "sorted-packets", "unsorted", "unsorted-packets",
+                 "default"):
         dev = scene_with(render, monkeypatch, blob, FORMS[form])
         frame, hits, st = dev.render(p, want_hits=True)
         frames.append(assert_matches_checker(frame, hits, st, want))
         assert st.env_lookups > 0 and st.rays_secondary > 0
         dev.close()
-    assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
-    assert np.array_equal(frames[1].view(np.uint32), frames[2].view(np.uint32))
+    for f in frames[:-1]:
+        assert np.array_equal(f.view(np.uint32), frames[-1].view(np.uint32))
 
 
 @pytest.mark.parametrize("idx", range(16))
@@ -117,12 +122,13 @@ def test_random_reflective_scenes_through_every_form(render, monkeypatch, tmp_pa
     p = render.make_params(rng_mode=_abi.RNG_KEYED)
     want = oracle_lib.OracleScene(blob).render(rng_mode=_abi.RNG_KEYED, want_hits=True, threads=8)
     frames = {}
-    for form in ("per-lane-sorted", "unsorted", "default"):
+    forms = ("per-lane-sorted", "sorted-packets", "unsorted", "unsorted-packets")
+    for form in forms + ("default",):
         dev = scene_with(render, monkeypatch, blob, FORMS[form])
         frame, hits, st = dev.render(p, want_hits=True)
         frames[form] = assert_matches_checker(frame, hits, st, want)
         dev.close()
-    for form in ("per-lane-sorted", "unsorted"):
+    for form in forms:
         assert np.array_equal(frames[form].view(np.uint32), frames["default"].view(np.uint32)), form
 
 
