@@ -34,9 +34,14 @@ namespace {
 
 int g_device = -1;
 
-const unsigned QUEUE_CAPACITY_MAX = 1u << 26;   // rays per bounce queue (80 B each)
+// Rays per bounce queue (80 B each; three queues and 48 B of sort scratch per entry: 77 GB
+// at the limit, a quarter of the GPU's memory).  Large queues are not only fewer
+// launches: the more hits a bounce level holds, the closer together lie the 64 hits
+// that share a wave after sorting, and the cheaper their shadow rays become (8-glossy at
+// 640 x 640 x 64 samples: 233 ms in four chunks, 190 ms in one).
+const unsigned QUEUE_CAPACITY_MAX = 1u << 28;
+const unsigned QUEUE_CAPACITY_LIMIT = 1u << 28;
 const unsigned QUEUE_CAPACITY_MIN = 1u << 16;
-const unsigned RT_SCAN_MAX_SEGMENTS = 4096;     // what k_scan_of_sums handles
 const unsigned long long GLIBC_TABLE_DRAWS_DEFAULT = 1ull << 24;   // serial-stream table: 64 MiB
 const unsigned long long GLIBC_TABLE_DRAWS_MAX = 1ull << 28;
 
@@ -67,7 +72,7 @@ struct rtamd_scene {
 	unsigned *d_qcount = nullptr;
 	DevCounters *d_counters = nullptr;
 	// coherent bounce pass (see kernels.hip): per-entry scratch sized like the queues
-	BounceWork bounce = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 1, 0 };
+	BounceWork bounce = { nullptr, { nullptr, nullptr }, { nullptr, nullptr }, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0xffffffffu };
 	unsigned bounce_capacity = 0;
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	bool bounce_packets = false; // unsorted pass: queued rays walk as wave-wide packets (mirror-only scenes)
@@ -188,11 +193,13 @@ static int take_sticky_overflow(rtamd_scene *sc);
 static void free_bounce_work(rtamd_scene *sc)
 {
 	BounceWork &w = sc->bounce;
-	void *ptrs[] = { w.hits, w.bins, w.perm, w.hist, w.sums, w.bounds };
+	void *ptrs[] = { w.hits, w.keys[0], w.keys[1], w.index[0], w.index[1], w.counts, w.totals, w.bounds };
 	for (void *p : ptrs)
 		if (p)
 			(void)hipFree(p);
-	w = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.bits, w.small_below, w.hits_per_wave, w.shade_packets };
+	w.hits = nullptr;
+	w.keys[0] = w.keys[1] = w.index[0] = w.index[1] = nullptr;
+	w.counts = w.totals = w.bounds = nullptr;
 	sc->bounce_capacity = 0;
 }
 
@@ -342,7 +349,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		if (mode && !strcmp(mode, "sorted")) sc->sorted_bounce = true;
 		if (mode && !strcmp(mode, "legacy")) sc->sorted_bounce = false;
 		const char *bits = getenv("RTAMD_SORT_BITS");
-		int b = bits ? atoi(bits) : 7;
+		int b = bits ? atoi(bits) : 9;
 		sc->bounce.bits = b < 1 ? 1 : (b > RT_SORT_BITS_MAX ? RT_SORT_BITS_MAX : b);
 		// Levels of fewer hits than this (RTAMD_SMALL_LEVEL, 0 = never) are shaded with each
 		// hit's light samples across the lanes of a wave: as many hits to a wave as have
@@ -357,8 +364,14 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		sc->bounce_packets = !any_glossy && d.spp >= 64;
 		if (walk && !strcmp(walk, "packet")) sc->bounce_packets = true;
 		if (walk && !strcmp(walk, "lane")) sc->bounce_packets = false;
+		// Levels of at least this many hits (RTAMD_PACKETS_FROM; RTAMD_BOUNCE_SHADE=packet: all
+		// that are not "small", =lane: none) are shaded with wave-wide shafts and packets.
+		const char *from = getenv("RTAMD_PACKETS_FROM");
+		sc->bounce.packets_from = from ? (unsigned)strtoul(from, nullptr, 0) : (1u << 21);
 		const char *shade = getenv("RTAMD_BOUNCE_SHADE");
-		sc->bounce.shade_packets = shade && !strcmp(shade, "packet");
+		if (shade && !strcmp(shade, "packet")) sc->bounce.packets_from = 0;
+		if (shade && !strcmp(shade, "lane")) sc->bounce.packets_from = 0xffffffffu;
+		sc->bounce.sort_chunks_max = 2048;
 		const int m = h.shadow_samples * h.shadow_samples;
 		int per_wave = m >= 64 ? 1 : 64 / m;
 		sc->bounce.hits_per_wave = (unsigned)(per_wave > 8 ? 8 : per_wave);
@@ -576,7 +589,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		// rules out.
 		const char *cap = getenv("RTAMD_QUEUE_CAPACITY");
 		const unsigned long long c = cap ? strtoull(cap, nullptr, 0) : 0;
-		sc->queue_capacity_max = c >= RT_BLOCK && c < QUEUE_CAPACITY_MAX ? (unsigned)c : QUEUE_CAPACITY_MAX;
+		sc->queue_capacity_max = c >= RT_BLOCK && c <= QUEUE_CAPACITY_LIMIT ? (unsigned)c : QUEUE_CAPACITY_MAX;
 		const char *at = getenv("RTAMD_QUEUE_OVERFLOW_AT");
 		sc->overflow_test_capacity = at ? (unsigned)strtoul(at, nullptr, 0) : 0;
 		// RTAMD_GLIBC_TABLE_DRAWS bounds the serial-stream table (frames are then rendered
@@ -1136,34 +1149,59 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 		unsigned long long want = samples * vertex_fan(sc);
 		unsigned cap = want > sc->queue_capacity_max ? sc->queue_capacity_max
 				: (want < QUEUE_CAPACITY_MIN ? QUEUE_CAPACITY_MIN : (unsigned)want);
-		if (sc->queue_capacity < cap) {
+		const bool want_sorted = sc->sorted_bounce;
+		if (sc->queue_capacity < cap || (want_sorted && sc->bounce_capacity < sc->queue_capacity)) {
 			HIP_TRY(hipStreamSynchronize(stream));
-			for (int q = 0; q < 3; q++) {
-				if (sc->d_queue[q])
-					(void)hipFree(sc->d_queue[q]);
-				sc->d_queue[q] = nullptr;
-			}
-			sc->queue_capacity = 0;
-			for (int q = 0; q < 3; q++) {
+			// A capacity the device cannot give (other processes share it, or the frame asks for
+			// the limit) is halved until the buffers fit: smaller queues only mean more chunks.
+			const unsigned floor_cap = (unsigned)(vertex_fan(sc) * RT_BLOCK > QUEUE_CAPACITY_MIN ? vertex_fan(sc) * RT_BLOCK
+					: QUEUE_CAPACITY_MIN);
+			unsigned try_cap = cap > sc->queue_capacity ? cap : sc->queue_capacity;
+			for (;;) {
+				for (int q = 0; q < 3; q++) {
+					if (sc->d_queue[q])
+						(void)hipFree(sc->d_queue[q]);
+					sc->d_queue[q] = nullptr;
+				}
+				sc->queue_capacity = 0;
+				free_bounce_work(sc);
+				hipError_t e = hipSuccess;
 				void *ptr = nullptr;
-				HIP_TRY(hipMalloc(&ptr, (size_t)cap * sizeof(QueueItem)));
-				sc->d_queue[q] = static_cast<QueueItem *>(ptr);
+				for (int q = 0; q < 3 && e == hipSuccess; q++) {
+					e = hipMalloc(&ptr, (size_t)try_cap * sizeof(QueueItem));
+					if (e == hipSuccess)
+						sc->d_queue[q] = static_cast<QueueItem *>(ptr);
+				}
+				if (e == hipSuccess && want_sorted) {
+					const size_t n = try_cap;
+					BounceWork &bw = sc->bounce;
+					auto take = [&](size_t bytes, void **out) {
+						if (e == hipSuccess && (e = hipMalloc(&ptr, bytes)) == hipSuccess)
+							*out = ptr;
+					};
+					take(n * sizeof(BounceHit), reinterpret_cast<void **>(&bw.hits));
+					for (int k = 0; k < 2; k++) {
+						take(n * sizeof(unsigned), reinterpret_cast<void **>(&bw.keys[k]));
+						take(n * sizeof(unsigned), reinterpret_cast<void **>(&bw.index[k]));
+					}
+					take((size_t)RT_SORT_RADIX * bw.sort_chunks_max * sizeof(unsigned), reinterpret_cast<void **>(&bw.counts));
+					take(RT_SORT_RADIX * sizeof(unsigned), reinterpret_cast<void **>(&bw.totals));
+					take(8 * sizeof(unsigned), reinterpret_cast<void **>(&bw.bounds));
+				}
+				if (e == hipSuccess) {
+					sc->queue_capacity = try_cap;
+					if (want_sorted)
+						sc->bounce_capacity = try_cap;
+					break;
+				}
+				(void)hipGetLastError();      // the failed allocation is dealt with here
+				if (e != hipErrorOutOfMemory || try_cap / 2 < floor_cap) {
+					rtamd_set_error("allocating ray queues of %u entries failed: %s", try_cap, hipGetErrorString(e));
+					return RTAMD_ERR_HIP;
+				}
+				try_cap /= 2;
+				try_cap -= try_cap % RT_BLOCK;
 			}
-			sc->queue_capacity = cap;
-		}
-		if (sc->sorted_bounce && sc->bounce_capacity < sc->queue_capacity) {
-			HIP_TRY(hipStreamSynchronize(stream));
-			free_bounce_work(sc);
-			const size_t n = sc->queue_capacity;
-			const size_t n_bins = ((size_t)1 << (3 * sc->bounce.bits)) + 1;
-			void *ptr = nullptr;
-			HIP_TRY(hipMalloc(&ptr, n * sizeof(BounceHit)));   sc->bounce.hits = static_cast<BounceHit *>(ptr);
-			HIP_TRY(hipMalloc(&ptr, n * sizeof(BounceBin)));   sc->bounce.bins = static_cast<BounceBin *>(ptr);
-			HIP_TRY(hipMalloc(&ptr, n * sizeof(unsigned)));    sc->bounce.perm = static_cast<unsigned *>(ptr);
-			HIP_TRY(hipMalloc(&ptr, n_bins * sizeof(unsigned)));  sc->bounce.hist = static_cast<unsigned *>(ptr);
-			HIP_TRY(hipMalloc(&ptr, RT_SCAN_MAX_SEGMENTS * sizeof(unsigned))); sc->bounce.sums = static_cast<unsigned *>(ptr);
-			HIP_TRY(hipMalloc(&ptr, 8 * sizeof(unsigned)));    sc->bounce.bounds = static_cast<unsigned *>(ptr);
-			sc->bounce_capacity = sc->queue_capacity;
 		}
 	}
 	RenderWork w;
@@ -1242,25 +1280,25 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 				sc->device);
 		return RTAMD_ERR_ARG;
 	}
-	// Layout: counters | queue counters | hit-point bounds | scan sums | histogram |
-	// accumulators | queue 0 | queue 1 | hits | bins | order.
+	// Layout: counters | queue counters | hit-point bounds | digit totals | digit counts |
+	// accumulators | queues 0 1 2 | hits | sort keys and indices (two of each).
 	const bool sorted = sc->sorted_bounce && sc->dev.any_reflective;
-	const int bits = sc->bounce.bits < 6 ? sc->bounce.bits : 6;
-	const size_t n_bins = ((size_t)1 << (3 * bits)) + 1;
+	const unsigned chunks_max = 256;      // wave-chunks of the hit sort: 1 MiB of digit counts
 	size_t off = 0;
 	RenderWork w;
 	std::memset(&w, 0, sizeof w);
 	w.counters = reinterpret_cast<DevCounters *>(base + off);  off = align_up(off + sizeof(DevCounters) * RT_COUNTER_COPIES, 256);
 	w.qcount = reinterpret_cast<unsigned *>(base + off);       off = align_up(off + 128 * sizeof(unsigned), 256);
 	w.bounce.bounds = reinterpret_cast<unsigned *>(base + off); off = align_up(off + 8 * sizeof(unsigned), 256);
-	w.bounce.sums = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + RT_SCAN_MAX_SEGMENTS * sizeof(unsigned), 256);
-	w.bounce.bits = bits;
+	w.bounce.totals = reinterpret_cast<unsigned *>(base + off);  off = align_up(off + RT_SORT_RADIX * sizeof(unsigned), 256);
+	w.bounce.bits = sc->bounce.bits;
 	w.bounce.small_below = sc->bounce.small_below;
 	w.bounce.hits_per_wave = sc->bounce.hits_per_wave;
-	w.bounce.shade_packets = sc->bounce.shade_packets;
+	w.bounce.packets_from = sc->bounce.packets_from;
+	w.bounce.sort_chunks_max = chunks_max;
 	if (sorted) {
-		w.bounce.hist = reinterpret_cast<unsigned *>(base + off);
-		off = align_up(off + n_bins * sizeof(unsigned), 256);
+		w.bounce.counts = reinterpret_cast<unsigned *>(base + off);
+		off = align_up(off + (size_t)RT_SORT_RADIX * chunks_max * sizeof(unsigned), 256);
 	}
 	const bool streamed = p.rng_mode == RTAMD_RNG_GLIBC && sc->dev.antialiasing;
 	if (streamed) {
@@ -1318,8 +1356,8 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		off = align_up(off + bytes, 256);
 	}
 	if (sc->dev.any_reflective) {
-		const size_t per_entry = 3 * sizeof(QueueItem) + (sorted ? sizeof(BounceHit) + sizeof(BounceBin) + sizeof(unsigned) : 0);
-		size_t cap = (RTAMD_NOALLOC_SCRATCH_BYTES - off - 6 * 256) / per_entry;
+		const size_t per_entry = 3 * sizeof(QueueItem) + (sorted ? sizeof(BounceHit) + 4 * sizeof(unsigned) : 0);
+		size_t cap = (RTAMD_NOALLOC_SCRATCH_BYTES - off - 8 * 256) / per_entry;
 		cap -= cap % 256;
 		// as rtamd_render sizes its queues: what the call's samples can spawn, but never
 		// less than the floor that keeps a chunk at a workgroup or more
@@ -1342,8 +1380,10 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 		w.queue[2] = reinterpret_cast<QueueItem *>(base + off);  off = align_up(off + cap * sizeof(QueueItem), 256);
 		if (sorted) {
 			w.bounce.hits = reinterpret_cast<BounceHit *>(base + off);  off = align_up(off + cap * sizeof(BounceHit), 256);
-			w.bounce.bins = reinterpret_cast<BounceBin *>(base + off);  off = align_up(off + cap * sizeof(BounceBin), 256);
-			w.bounce.perm = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + cap * sizeof(unsigned), 256);
+			for (int k = 0; k < 2; k++) {
+				w.bounce.keys[k] = reinterpret_cast<unsigned *>(base + off);   off = align_up(off + cap * sizeof(unsigned), 256);
+				w.bounce.index[k] = reinterpret_cast<unsigned *>(base + off);  off = align_up(off + cap * sizeof(unsigned), 256);
+			}
 		}
 	}
 	if (off > RTAMD_NOALLOC_SCRATCH_BYTES) {

@@ -18,19 +18,21 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
 		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
 /* Scratch of one bounce level of the coherent pass: per queue entry the nearest
- * hit, its bin and the sorted order; the bin histogram ((2^bits)^3 + 1 entries,
- * scanned in place), the per-segment sums of the scan, the hit-point bounds. */
+ * hit; two buffers of (key, queue index) pairs for the radix sort of the hits; the
+ * sort's digit counts per wave-chunk and digit totals; eight words for the hit-point
+ * bounds, the batch cursor and the hit counter. */
 struct BounceWork {
 	BounceHit *hits;
-	BounceBin *bins;
-	unsigned *perm;
-	unsigned *hist;
-	unsigned *sums;
+	unsigned *keys[2];
+	unsigned *index[2];
+	unsigned *counts;        /* RT_SORT_RADIX x sort_chunks_max */
+	unsigned *totals;        /* RT_SORT_RADIX */
 	unsigned *bounds;
-	int bits;
+	int bits;                /* grid bits per axis of the sort key */
+	unsigned sort_chunks_max;/* wave-chunks the sort may use */
 	unsigned small_below;    /* levels of fewer hits are shaded with their samples across lanes; 0 = never */
 	unsigned hits_per_wave;  /* ... this many hits to a wave */
-	int shade_packets;       /* sorted hits are shaded with wave-wide shafts and packets instead of per-lane walks */
+	unsigned packets_from;   /* levels of at least this many hits are shaded with wave-wide shafts and packets */
 };
 hipError_t rt_launch_bounce(const DevScene &sc, const QueueSlice &in, long long *accum, QueueItem *queue_out,
 		unsigned *queue_out_count, DevCounters *counters, unsigned grid_blocks, bool packets, hipStream_t stream);

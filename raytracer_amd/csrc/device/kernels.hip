@@ -302,10 +302,9 @@ k_bounce(DevScene sc, QueueSlice in, unsigned queue_capacity,
 //   k_bounce_trace   one lane per queued ray: nearest hit with a per-lane BVH
 //                    walk; misses are shaded here (environment / background);
 //                    the bounds of all hit points are collected;
-//   k_bounce_bin, k_scan_*, k_bounce_scatter
-//                    counting sort of the hits by the Morton code of their
-//                    position in a grid over those bounds (the arrival number
-//                    an atomic returns is the rank inside the bin);
+//   k_hit_keys, k_sort_*
+//                    the hits, compacted, are radix-sorted by the Morton code of
+//                    their position in a grid over those bounds;
 //   k_bounce_shade   one lane per hit in sorted order: a wave holds 64
 //                    neighbouring hit points whose shadow rays, each walked by
 //                    its own lane, visit the same nodes and triangles at the
@@ -404,7 +403,7 @@ k_bounce_trace(DevScene sc, QueueSlice in, long long *accum, BounceHit *bhit, un
 
 DEV unsigned spread3(unsigned v)
 {
-	// 8 bits -> every third bit
+	// 10 bits -> every third bit
 	v = (v | (v << 16)) & 0x030000ffu;
 	v = (v | (v << 8)) & 0x0300f00fu;
 	v = (v | (v << 4)) & 0x030c30c3u;
@@ -412,14 +411,39 @@ DEV unsigned spread3(unsigned v)
 	return v;
 }
 
-// Bin of every hit: Morton code of its cell in a (2^bits)^3 grid over the bounds
-// of this level's hit points.  Misses and unused slots carry the number of the extra
-// last bin and take no rank: that bin's scanned offset is the number of hits, its
-// own population is never needed, and every wave adding to it would queue on one
-// address.
-__global__ void k_bounce_bin(QueueSlice in, const BounceHit *bhit, const unsigned *bounds, unsigned *hist,
-		BounceBin *bbin, int bits)
+// ---- spatial order of a level's hits -----------------------------------------------
+//
+// The hits are compacted into (key, queue index) pairs and sorted by key: the Morton
+// code of the hit point's cell in a (2^bits)^3 grid over the bounds of this level's hit
+// points (up to 10 bits per axis: cells of a hundredth of a unit, the footprint of a
+// pixel, so that 64 consecutive hits of a dense level lie as close together as the 64
+// samples of a primary pixel).  Least-significant-digit radix sort, RT_SORT_DIGIT bits
+// per pass; the number of pairs is only known on the device, so every kernel is
+// launched over a fixed grid and derives its share from the counter.  The unit of work
+// is a "wave-chunk": a contiguous run of pairs that one wave walks in order, which is
+// what makes the scatter stable.
+//
+// bounds[7] holds the number of hits minus one (all eight words start at 0xffffffff).
+
+DEV unsigned sort_pairs(const unsigned *bounds) { return bounds[7] + 1u; }
+
+// wave-chunks in use and pairs per chunk (a multiple of 64) for n pairs
+DEV void sort_chunks(unsigned n, unsigned w_max, unsigned &chunks, unsigned &per)
 {
+	// at least 1024 pairs to a chunk, at most w_max chunks
+	unsigned c = (n + 1023u) / 1024u;
+	if (c > w_max) c = w_max;
+	if (c < 1u) c = 1u;
+	per = (n + c - 1u) / c;
+	per = (per + 63u) & ~63u;
+	if (per < 64u) per = 64u;
+	chunks = (n + per - 1u) / per;
+}
+
+__global__ void __launch_bounds__(256)
+k_hit_keys(QueueSlice in, const BounceHit *bhit, unsigned *bounds, unsigned *keys, unsigned *index, int bits)
+{
+	__shared__ unsigned s_wave_hits[4], s_block_base;
 	const QueueItem *queue_in = in.items + in.first;
 	const unsigned count = slice_count(in);
 	const unsigned cells = 1u << bits;
@@ -434,11 +458,12 @@ __global__ void k_bounce_bin(QueueSlice in, const BounceHit *bhit, const unsigne
 	const unsigned rounds = (count + stride - 1) / stride;
 	for (unsigned round = 0; round < rounds; round++) {
 		const unsigned idx = round * stride + blockIdx.x * blockDim.x + threadIdx.x;
-		const bool active = idx < count;
-		unsigned key = 1u << (3 * bits);
-		if (active) {
+		bool hit = false;
+		unsigned key = 0;
+		if (idx < count) {
 			const BounceHit h = bhit[idx];
 			if (h.surface >= 0) {
+				hit = true;
 				const QueueItem &it = queue_in[idx];
 				unsigned c[3];
 				for (int a = 0; a < 3; a++) {
@@ -449,43 +474,32 @@ __global__ void k_bounce_bin(QueueSlice in, const BounceHit *bhit, const unsigne
 				key = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
 			}
 		}
-		// Neighbouring queue entries are children of one pixel and mostly land in the
-		// same bin: the lanes of a wave that share a key take their ranks from ONE
-		// atomic (thousands of single increments on one address serialise in L2).
-		// First the lanes sort themselves into groups of equal keys (no memory access),
-		// then the first lane of every group reserves the group's ranks: one atomic
-		// instruction per wave and turn, whose round trip is waited for once.
-		unsigned first_lane = 0, before = 0, group = 0;
-		const unsigned no_bin = 1u << (3 * bits);
-		const bool ranked = active && key != no_bin;
-		u64 todo = __builtin_amdgcn_ballot_w64(ranked);
-		while (todo) {
-			const int leader = __builtin_ctzll(todo);
-			const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)key, leader);
-			const u64 same = __builtin_amdgcn_ballot_w64(ranked && key == k) & todo;
-			if (ranked && key == k) {
-				first_lane = (unsigned)leader;
-				before = (unsigned)__builtin_popcountll(same & ((1ull << lane_id()) - 1ull));
-				group = (unsigned)__builtin_popcountll(same);
+		// one reservation per workgroup and round (a frame's levels hold tens of millions
+		// of hits: one atomic per wave on the one counter would take longer than the rest)
+		const u64 hits = __builtin_amdgcn_ballot_w64(hit);
+		const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
+		if (lane == 0)
+			s_wave_hits[wave] = (unsigned)__builtin_popcountll(hits);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned total = 0;
+			for (unsigned w = 0; w < 4; w++) {
+				const unsigned c = s_wave_hits[w];
+				s_wave_hits[w] = total;
+				total += c;
 			}
-			todo &= ~same;
+			s_block_base = total ? atomicAdd(&bounds[7], total) + 1u : 0u;
 		}
-		unsigned base = 0;
-		if (ranked && lane_id() == first_lane)
-			base = atomicAdd(&hist[key], group);
-		base = (unsigned)__shfl((int)base, (int)first_lane, 64);
-		const unsigned rank = base + before;
-		if (active) {
-			BounceBin b;
-			b.key = key;
-			b.rank = rank;
-			bbin[idx] = b;
+		__syncthreads();
+		if (hit) {
+			const unsigned at = s_block_base + s_wave_hits[wave] + (unsigned)__builtin_popcountll(hits & ((1ull << lane) - 1ull));
+			keys[at] = key;
+			index[at] = idx;
 		}
+		__syncthreads();
 	}
 }
 
-// Exclusive scan of the histogram in three steps: per-segment sums, a scan of the
-// sums by one workgroup, per-segment scans with the segment's offset.
 DEV unsigned block_exclusive_scan(unsigned v, unsigned *s_wave, unsigned &block_total)
 {
 	const unsigned lane = lane_id(), wave = threadIdx.x >> 6;
@@ -510,75 +524,120 @@ DEV unsigned block_exclusive_scan(unsigned v, unsigned *s_wave, unsigned &block_
 	return before + incl - v;
 }
 
+// counts[digit * w_max + chunk] = pairs of the chunk with that digit
 __global__ void __launch_bounds__(256)
-k_scan_sums(const unsigned *hist, unsigned n, unsigned *sums)
+k_sort_count(const unsigned *keys, const unsigned *bounds, unsigned w_max, int shift, unsigned *counts)
 {
-	__shared__ unsigned s_wave[4];
-	const unsigned first = blockIdx.x * RT_SCAN_SEGMENT;
-	unsigned v = 0;
-	for (unsigned i = threadIdx.x; i < RT_SCAN_SEGMENT; i += 256)
-		if (first + i < n)
-			v += hist[first + i];
-	unsigned total;
-	block_exclusive_scan(v, s_wave, total);
-	if (threadIdx.x == 0)
-		sums[blockIdx.x] = total;
+	__shared__ unsigned s_cnt[4][RT_SORT_RADIX];
+	const unsigned n = sort_pairs(bounds);
+	unsigned chunks, per;
+	sort_chunks(n, w_max, chunks, per);
+	const unsigned wave = threadIdx.x >> 6, lane = lane_id();
+	const unsigned chunk = blockIdx.x * 4u + wave;
+	if (chunk >= chunks || n == 0)
+		return;
+	for (unsigned d = lane; d < RT_SORT_RADIX; d += 64)
+		s_cnt[wave][d] = 0;
+	const unsigned first = chunk * per, last = first + per < n ? first + per : n;
+	for (unsigned i = first + lane; i < last; i += 64)
+		atomicAdd(&s_cnt[wave][(keys[i] >> shift) & (RT_SORT_RADIX - 1)], 1u);
+	for (unsigned d = lane; d < RT_SORT_RADIX; d += 64)
+		counts[(size_t)d * w_max + chunk] = s_cnt[wave][d];
 }
 
-// one workgroup; n_sums <= 256 * 16
+// One workgroup per digit: exclusive scan of the digit's chunk counts in place, and
+// the digit's total.
 __global__ void __launch_bounds__(256)
-k_scan_of_sums(unsigned *sums, unsigned n_sums)
+k_sort_scan(unsigned *counts, const unsigned *bounds, unsigned w_max, unsigned *totals)
 {
 	__shared__ unsigned s_wave[4];
-	unsigned v[16], mine = 0;
-	for (int k = 0; k < 16; k++) {
-		const unsigned i = threadIdx.x * 16 + k;
-		v[k] = i < n_sums ? sums[i] : 0;
-		mine += v[k];
-	}
+	const unsigned n = sort_pairs(bounds);
+	unsigned chunks, per;
+	sort_chunks(n, w_max, chunks, per);
+	unsigned *row = counts + (size_t)blockIdx.x * w_max;
+	const unsigned each = (chunks + 255u) / 256u;
+	const unsigned first = threadIdx.x * each;
+	unsigned mine = 0;
+	for (unsigned k = 0; k < each; k++)
+		if (first + k < chunks && n)
+			mine += row[first + k];
 	unsigned total;
 	unsigned run = block_exclusive_scan(mine, s_wave, total);
-	for (int k = 0; k < 16; k++) {
-		const unsigned i = threadIdx.x * 16 + k;
-		if (i < n_sums)
-			sums[i] = run;
-		run += v[k];
-	}
+	for (unsigned k = 0; k < each; k++)
+		if (first + k < chunks && n) {
+			const unsigned c = row[first + k];
+			row[first + k] = run;
+			run += c;
+		}
+	if (threadIdx.x == 0)
+		totals[blockIdx.x] = n ? total : 0;
 }
 
+// Stable scatter: a wave walks its chunk in order, 64 pairs at a time; a pair's rank
+// among the equal digits of its tile is the number of lower lanes with that digit
+// (one ballot per digit bit), the digit's running position lives in LDS.
 __global__ void __launch_bounds__(256)
-k_scan_segments(unsigned *hist, unsigned n, const unsigned *sums)
+k_sort_scatter(const unsigned *keys_in, const unsigned *index_in, const unsigned *bounds, unsigned w_max, int shift,
+		const unsigned *counts, const unsigned *totals, unsigned *keys_out, unsigned *index_out)
 {
+	__shared__ unsigned s_next[4][RT_SORT_RADIX];
+	__shared__ unsigned s_base[RT_SORT_RADIX];
 	__shared__ unsigned s_wave[4];
-	const unsigned per = RT_SCAN_SEGMENT / 256;
-	const unsigned first = blockIdx.x * RT_SCAN_SEGMENT + threadIdx.x * per;
-	unsigned v[per], mine = 0;
-	for (unsigned k = 0; k < per; k++) {
-		v[k] = first + k < n ? hist[first + k] : 0;
-		mine += v[k];
+	const unsigned n = sort_pairs(bounds);
+	unsigned chunks, per;
+	sort_chunks(n, w_max, chunks, per);
+	if (n == 0 || blockIdx.x * 4u >= chunks)
+		return;
+	// exclusive scan of the digit totals: where each digit's pairs start
+	{
+		const unsigned each = RT_SORT_RADIX / 256;
+		unsigned v[each], mine = 0;
+		for (unsigned k = 0; k < each; k++) {
+			v[k] = totals[threadIdx.x * each + k];
+			mine += v[k];
+		}
+		unsigned total;
+		unsigned run = block_exclusive_scan(mine, s_wave, total);
+		for (unsigned k = 0; k < each; k++) {
+			s_base[threadIdx.x * each + k] = run;
+			run += v[k];
+		}
 	}
-	unsigned total;
-	unsigned run = sums[blockIdx.x] + block_exclusive_scan(mine, s_wave, total);
-	for (unsigned k = 0; k < per; k++) {
-		if (first + k < n)
-			hist[first + k] = run;
-		run += v[k];
+	__syncthreads();
+	const unsigned wave = threadIdx.x >> 6, lane = lane_id();
+	const unsigned chunk = blockIdx.x * 4u + wave;
+	if (chunk >= chunks)
+		return;
+	for (unsigned d = lane; d < RT_SORT_RADIX; d += 64)
+		s_next[wave][d] = s_base[d] + counts[(size_t)d * w_max + chunk];
+	const unsigned first = chunk * per, last = first + per < n ? first + per : n;
+	const u64 below = (1ull << lane) - 1ull;
+	for (unsigned base = first; base < last; base += 64) {
+		const unsigned i = base + lane;
+		const bool valid = i < last;
+		const unsigned key = valid ? keys_in[i] : 0u, idx = valid ? index_in[i] : 0u;
+		const unsigned digit = (key >> shift) & (RT_SORT_RADIX - 1);
+		u64 same = __builtin_amdgcn_ballot_w64(valid);
+		for (int k = 0; k < RT_SORT_DIGIT; k++) {
+			const bool bit = (digit >> k) & 1u;
+			const u64 with = __builtin_amdgcn_ballot_w64(bit);
+			same &= bit ? with : ~with;
+		}
+		if (valid) {
+			const unsigned start = s_next[wave][digit];
+			const unsigned rank = (unsigned)__builtin_popcountll(same & below);
+			const unsigned dest = start + rank;
+			// the last lane of the group moves the digit on (all lanes of the group have read it:
+			// a wave's LDS accesses complete in program order)
+			if (rank + 1u == (unsigned)__builtin_popcountll(same))
+				s_next[wave][digit] = start + rank + 1u;
+			keys_out[dest] = key;
+			index_out[dest] = idx;
+		}
 	}
 }
 
-__global__ void k_bounce_scatter(QueueSlice in, const BounceBin *bbin, const unsigned *offsets, unsigned *perm,
-		unsigned no_bin)
-{
-	const unsigned count = slice_count(in);
-	const unsigned stride = gridDim.x * blockDim.x;
-	for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += stride) {
-		const BounceBin b = bbin[idx];
-		if (b.key != no_bin)
-			perm[offsets[b.key] + b.rank] = idx;
-	}
-}
-
-// `n_hits` points at the scanned offset of the extra last bin = the number of hits.
+// `n_hits` points at the number of hits minus one (the counter k_hit_keys leaves).
 // Shadow rays are walked per lane: measured on 8-glossy (640^2, 64 spp) 384 ms per
 // frame against 451 ms with wave-wide shafts and packets (the shaft of 64 distinct
 // hit points next to a mesh holds too many leaves, and a packet of their rays is
@@ -588,7 +647,7 @@ __global__ void k_bounce_scatter(QueueSlice in, const BounceBin *bbin, const uns
 // levels go to k_bounce_shade_small.
 template <bool PACKET>
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES_BOUNCE)
-k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, unsigned min_hits,
+k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, unsigned min_hits, unsigned max_hits,
 		const BounceHit *bhit, const unsigned *perm, unsigned queue_capacity, long long *accum, QueueItem *queue_out,
 		unsigned *queue_out_count, DevCounters *counters, unsigned *cursor)
 {
@@ -602,10 +661,10 @@ k_bounce_shade(DevScene sc, const QueueItem *queue_in, const unsigned *n_hits, u
 		s_timing[threadIdx.x >> 6][threadIdx.x & 63] = 0;
 #endif
 	TM_BEGIN(t_kernel);
-	unsigned count = *n_hits;
+	unsigned count = *n_hits + 1u;
 	if (count > queue_capacity)
 		count = queue_capacity;
-	if (count < min_hits)
+	if (count < min_hits || count >= max_hits)
 		return;
 	ShadeIO io = { &sc, RTAMD_RNG_KEYED, queue_out, queue_out_count, queue_capacity, counters,
 		PACKET ? s_shaft[threadIdx.x >> 6] : nullptr, nullptr, nullptr };
@@ -684,7 +743,7 @@ k_bounce_shade_small(DevScene sc, const QueueItem *queue_in, const unsigned *n_h
 	__shared__ int4 s_wave_stack[(RT_BLOCK / 64) * RT_MAX_STACK];
 	__shared__ float s_wave_sum[RT_BLOCK / 64][384];
 	int *stack = s_stack + threadIdx.x;
-	unsigned count = *n_hits;
+	unsigned count = *n_hits + 1u;
 	if (count > queue_capacity)
 		count = queue_capacity;
 	if (count >= max_hits)
@@ -764,6 +823,9 @@ k_collect_stats(DevCounters *counters)
 		if (g_stat_ev[i])
 			printf("event %d %llu\n", i, g_stat_ev[i]);
 		g_stat_ev[i] = 0;
+		if (g_stat_walk[i])
+			printf("walk %s steps<2^%d %llu\n", i & 1 ? "occluded" : "free", i / 2, g_stat_walk[i]);
+		g_stat_walk[i] = 0;
 	}
 #endif
 #ifdef RT_TIMING
@@ -1070,39 +1132,50 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, lon
 		hipStream_t stream)
 {
 	const int bits = work.bits;
-	const unsigned n_bins = (1u << (3 * bits)) + 1u;
-	const unsigned n_seg = (n_bins + RT_SCAN_SEGMENT - 1) / RT_SCAN_SEGMENT;
 	hipError_t e;
-	if ((e = hipMemsetAsync(work.hist, 0, (size_t)n_bins * sizeof(unsigned), stream)) != hipSuccess) return e;
+	// hit-point bounds, batch cursor, hit counter: all start at 0xffffffff
 	if ((e = hipMemsetAsync(work.bounds, 0xff, 8 * sizeof(unsigned), stream)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_bounce_trace, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, in, accum, work.hits,
 			work.bounds, counters);
-	hipLaunchKernelGGL(k_bounce_bin, dim3(grid_blocks), dim3(256), 0, stream, in, work.hits, work.bounds, work.hist,
-			work.bins, bits);
-	hipLaunchKernelGGL(k_scan_sums, dim3(n_seg), dim3(256), 0, stream, work.hist, n_bins, work.sums);
-	hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, stream, work.sums, n_seg);
-	hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(256), 0, stream, work.hist, n_bins, work.sums);
-	hipLaunchKernelGGL(k_bounce_scatter, dim3(grid_blocks), dim3(256), 0, stream, in, work.bins, work.hist, work.perm,
-			n_bins - 1u);
-	// levels of fewer hits than the GPU has lanes to give them are shaded by the kernel
-	// that spreads each hit's light samples over a wave
+	hipLaunchKernelGGL(k_hit_keys, dim3(grid_blocks), dim3(256), 0, stream, in, work.hits, work.bounds, work.keys[0],
+			work.index[0], bits);
+	const int passes = (3 * bits + RT_SORT_DIGIT - 1) / RT_SORT_DIGIT;
+	const unsigned sort_blocks = (work.sort_chunks_max + 3u) / 4u;
+	int from = 0;
+	for (int pass = 0; pass < passes; pass++) {
+		const int shift = pass * RT_SORT_DIGIT;
+		hipLaunchKernelGGL(k_sort_count, dim3(sort_blocks), dim3(256), 0, stream, work.keys[from], work.bounds,
+				work.sort_chunks_max, shift, work.counts);
+		hipLaunchKernelGGL(k_sort_scan, dim3(RT_SORT_RADIX), dim3(256), 0, stream, work.counts, work.bounds,
+				work.sort_chunks_max, work.totals);
+		hipLaunchKernelGGL(k_sort_scatter, dim3(sort_blocks), dim3(256), 0, stream, work.keys[from], work.index[from],
+				work.bounds, work.sort_chunks_max, shift, work.counts, work.totals, work.keys[1 - from],
+				work.index[1 - from]);
+		from = 1 - from;
+	}
+	const unsigned *perm = work.index[from];
+	// Three kernels share a level by its number of hits: the thinnest levels spread each
+	// hit's light samples over a wave, the middle ones walk per lane, dense ones - where 64
+	// neighbouring hits lie within a pixel's footprint of each other - in packets.
 	const unsigned small_below = work.small_below;
-	const unsigned *n_hits = work.hist + (n_bins - 1);
+	const unsigned packets_from = work.packets_from > small_below ? work.packets_from : small_below;
+	const unsigned *n_hits = work.bounds + 7;
 	const QueueItem *items = in.items + in.first;
-	if (work.shade_packets)
-		hipLaunchKernelGGL(k_bounce_shade<true>, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
-				small_below, work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters,
-				work.bounds + 6);
-	else
+	if (packets_from > small_below)
 		hipLaunchKernelGGL(k_bounce_shade<false>, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
-				small_below, work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters,
+				small_below, packets_from, work.hits, perm, in.capacity, accum, queue_out, queue_out_count, counters,
+				work.bounds + 6);
+	if (packets_from != 0xffffffffu)
+		hipLaunchKernelGGL(k_bounce_shade<true>, dim3(grid_blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
+				packets_from, 0xffffffffu, work.hits, perm, in.capacity, accum, queue_out, queue_out_count, counters,
 				work.bounds + 6);
 	if (small_below) {
 		const unsigned per_wave = work.hits_per_wave;
 		unsigned blocks = (small_below / per_wave + RT_BLOCK / 64 - 1) / (RT_BLOCK / 64);
 		if (blocks < 1) blocks = 1;
+		if (blocks > 65536) blocks = 65536;
 		hipLaunchKernelGGL(k_bounce_shade_small, dim3(blocks), dim3(RT_BLOCK), 0, stream, sc, items, n_hits,
-				small_below, per_wave, work.hits, work.perm, in.capacity, accum, queue_out, queue_out_count, counters);
+				small_below, per_wave, work.hits, perm, in.capacity, accum, queue_out, queue_out_count, counters);
 	}
 	return hipGetLastError();
 }

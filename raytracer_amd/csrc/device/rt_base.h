@@ -17,6 +17,10 @@
 #define RT_SHAFT_LISTS 4       // mesh surfaces (in traversal order) that get a list
 #endif
 
+#ifndef RT_ANYHIT_ORDER
+#define RT_ANYHIT_ORDER 0      // per-lane shadow walks: 0 nearer child first, 1 longer overlap first, 2 farther first
+#endif
+
 #ifdef RT_TRAVERSAL_STATS
 #define RT_STAT(x) x
 #else
@@ -50,6 +54,8 @@ __device__ unsigned long long g_stat_nodes, g_stat_tris;
 __device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
 // wave-level event counts: see the EV_ names
 __device__ unsigned long long g_stat_ev[32];
+// per-lane any-hit walks by length: [2k] unoccluded, [2k + 1] occluded, k = bit length of the step count
+__device__ unsigned long long g_stat_walk[32];
 enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,
 	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS,
 	// per-lane walks: walks started (per wave) and the lanes in them, loop iterations and the lanes in them

@@ -68,16 +68,22 @@ DEV PacketRay make_packet_ray(d3 o, d3 d, float tlo, float thi)
 // Conservative overlap test of the ray with a box inside [tlo, thi]; tn is the
 // (unwidened) entry distance, used only to order the children.
 DEV bool packet_box_hit(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
-		float tlo, float thi, float &tn)
+		float tlo, float thi, float &tn, float &tf)
 {
 	float ax = __builtin_fmaf(lox, r.ix, r.kx), bx = __builtin_fmaf(hix, r.ix, r.kx);
 	float ay = __builtin_fmaf(loy, r.iy, r.ky), by = __builtin_fmaf(hiy, r.iy, r.ky);
 	float az = __builtin_fmaf(loz, r.iz, r.kz), bz = __builtin_fmaf(hiz, r.iz, r.kz);
 	tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
 			__builtin_fminf(az, bz)), tlo);
-	float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+	tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
 			__builtin_fmaxf(az, bz)), thi);
 	return tn <= tf + r.slack;
+}
+DEV bool packet_box_hit(const PacketRay &r, float lox, float loy, float loz, float hix, float hiy, float hiz,
+		float tlo, float thi, float &tn)
+{
+	float tf;
+	return packet_box_hit(r, lox, loy, loz, hix, hiy, hiz, tlo, thi, tn, tf);
 }
 
 typedef unsigned long long u64;
@@ -158,19 +164,28 @@ DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear,
 	float limit = tfar;          // float upper bound of the search window, >= best_t
 	int sp = 0;
 	int ref = mesh.root;
+	RT_STAT(unsigned walk_steps = 0);
 	RT_STAT(if (ANYHIT) { RT_EV_ADD(EV_LANE_WALKS, 1); RT_EV_ADD(EV_LANE_WALK_LANES, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true))); });
 	for (;;) {
+		RT_STAT(walk_steps++);
 		RT_STAT(if (ANYHIT) { RT_EV_ADD(EV_LANE_STEPS, 1); RT_EV_ADD(EV_LANE_STEP_LANES, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true))); });
 		if (ref >= 0) {
 			RT_STAT(atomicAdd(&g_stat_nodes, 1ull));
 			const float4 q0 = nodes[4 * ref + 0], q1 = nodes[4 * ref + 1];
 			const float4 q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
-			float tn0, tn1;
-			bool h0 = packet_box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0);
-			bool h1 = packet_box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1);
+			float tn0, tn1, tf0, tf1;
+			bool h0 = packet_box_hit(br, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tnear, limit, tn0, tf0);
+			bool h1 = packet_box_hit(br, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tnear, limit, tn1, tf1);
 			int c0 = as_i(q3.x), c1 = as_i(q3.y);
 			if (h0 && h1) {
+#if RT_ANYHIT_ORDER == 1
+				// any hit will do: the child the ray spends more of its length in comes first
+				bool swap = ANYHIT ? (tf1 - tn1) > (tf0 - tn0) : tn1 < tn0;
+#elif RT_ANYHIT_ORDER == 2
+				bool swap = ANYHIT ? tn1 > tn0 : tn1 < tn0;
+#else
 				bool swap = tn1 < tn0;
+#endif
 				int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
 				if (sp < RT_MAX_STACK) {
 					stack[sp * RT_BLOCK] = farc;
@@ -204,8 +219,10 @@ DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear,
 					best_tri = first + i;
 					ba = aa; bb_ = bb; bc = cc;
 					found = true;
-					if (ANYHIT)
+					if (ANYHIT) {
+						RT_STAT(atomicAdd(&g_stat_walk[2 * (32 - __builtin_clz(walk_steps)) + 1 < 32 ? 2 * (32 - __builtin_clz(walk_steps)) + 1 : 31], 1ull));
 						return true;
+					}
 					// next float above or equal to t: boxes further than this cannot win
 					float ft = (float)t;
 					if ((double)ft < t)
@@ -219,6 +236,7 @@ DEV bool mesh_traverse(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float tnear,
 		sp--;
 		ref = stack[sp * RT_BLOCK];
 	}
+	RT_STAT(if (ANYHIT) atomicAdd(&g_stat_walk[2 * (32 - __builtin_clz(walk_steps)) < 30 ? 2 * (32 - __builtin_clz(walk_steps)) : 30], 1ull));
 	return found;
 }
 

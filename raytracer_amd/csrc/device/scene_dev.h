@@ -151,14 +151,9 @@ struct BounceHit {
 	uint32_t pad;
 };
 
-/* Spatial bin of a bounced hit and its arrival number inside the bin. */
-struct BounceBin {
-	uint32_t key;
-	uint32_t rank;
-};
-
-#define RT_SORT_BITS_MAX 8      /* bits per axis of the hit-point grid: at most 2^24 cells */
-#define RT_SCAN_SEGMENT 8192    /* histogram entries scanned by one workgroup */
+#define RT_SORT_BITS_MAX 10     /* bits per axis of the hit-point grid (30-bit Morton keys) */
+#define RT_SORT_DIGIT 10        /* bits per pass of the radix sort of the hits */
+#define RT_SORT_RADIX (1 << RT_SORT_DIGIT)
 
 /* A run of the reference's rand() stream in device memory: draws[i] is draw
  * number first + i. */
