@@ -18,7 +18,11 @@
 #endif
 
 #ifndef RT_ANYHIT_ORDER
-#define RT_ANYHIT_ORDER 0      // per-lane shadow walks: 0 nearer child first, 1 longer overlap first, 2 farther first
+// Per-lane shadow walks (any hit will do): 0 nearer child first, 1 the child the ray spends
+// more of its length in, 2 farther child first.  Measured on 8-glossy 640 x 640 x 64 with
+// every level walked per lane: 264 / 259 / 250 ms - occluders of a bounced hit's shadow
+// rays lie away from the hit point more often than next to it.
+#define RT_ANYHIT_ORDER 2
 #endif
 
 #ifdef RT_TRAVERSAL_STATS
