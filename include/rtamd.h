@@ -226,13 +226,31 @@ typedef struct rtamd_render_params {
 	 * whole frame); pixels outside it are left untouched. */
 	int32_t x0, y0, x1, y1;
 	int32_t flags;                  /* RTAMD_RENDER_* bits, 0 = none */
-	int32_t pad;
+	/* Sample subset (with RTAMD_RENDER_PROGRESSIVE): of every pixel's aa_samples^2
+	 * samples this call renders sample_count of those numbered sample_first,
+	 * sample_first + sample_stride, ... (count 0: all of them).  0 / 0 / 0 = all samples. */
+	int32_t sample_first, sample_stride;
+	int32_t sample_count;
 } rtamd_render_params;
 
 /* rtamd_render without `stats`: bracket every primary-kernel launch with HIP events on
  * the launch stream and keep them with the scene; rtamd_scene_take_kernel_times reads
  * them later.  The call stays asynchronous (no wait for the device per frame). */
 #define RTAMD_RENDER_TIME_KERNELS 1
+/* Progressive refinement, the role of the reference's rayviewer loop
+ * (rayviewer.c:128-150) with antialiasing: the scene keeps the frame's per-pixel sums
+ * from call to call; every call adds the samples of its subset (sample_first,
+ * sample_stride) and writes the frame scaled by the number of samples summed so far,
+ * so each call leaves a complete, noisier picture.  RTAMD_RENDER_RESTART clears the
+ * sums first (first pass of a frame).  Once every sample has been rendered the frame
+ * is, bit for bit, the one a single call renders.  Where the sample count divides 64
+ * (a pixel's samples share a wave and are added in float, in the reference's order,
+ * raytracer.c:41-46) the passes must keep that order: sample_stride 1, sample_first =
+ * the samples rendered so far, sample_count a divisor of 64.  Other sample counts are
+ * summed in 2^-32 fixed point, which commutes: any subsets in any order.
+ * Whole frame and all tiles only (tile_stride 1, no window), no hit records. */
+#define RTAMD_RENDER_PROGRESSIVE 2
+#define RTAMD_RENDER_RESTART 4
 
 typedef struct rtamd_render_stats {
 	uint64_t rays_primary;          /* ray_intersect-equivalent queries, by kind */

@@ -18,7 +18,7 @@ RTAMD_MAX_LIGHTS = 8
 SHAPE_PLANE, SHAPE_DISK, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_CONE, SHAPE_MESH = range(6)
 LIGHT_POINT, LIGHT_AREA = 0, 1
 RNG_GLIBC, RNG_KEYED = 0, 1
-RENDER_TIME_KERNELS = 1     # rtamd_render_params.flags
+RENDER_TIME_KERNELS, RENDER_PROGRESSIVE, RENDER_RESTART = 1, 2, 4     # rtamd_render_params.flags
 
 STATUS_NAMES = {
     0: "RTAMD_OK", -1: "RTAMD_ERR_ARG", -2: "RTAMD_ERR_IO", -3: "RTAMD_ERR_SCENE",
@@ -88,7 +88,8 @@ class RenderParams(C.Structure):
                 ("tile_w", C.c_int32), ("tile_h", C.c_int32),
                 ("tile_first", C.c_int32), ("tile_stride", C.c_int32),
                 ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
-                ("flags", C.c_int32), ("pad", C.c_int32)]
+                ("flags", C.c_int32), ("sample_first", C.c_int32), ("sample_stride", C.c_int32),
+                ("sample_count", C.c_int32)]
 
 
 class RenderStats(C.Structure):

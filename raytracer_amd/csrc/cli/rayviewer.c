@@ -2,7 +2,8 @@
  * rayviewer -- the progressive caller: the place of the reference's rayviewer.c,
  * without its SDL-1.2 window.
  *
- *   rayviewer scene.sdl [--passes N] [--dump PREFIX] [--assets DIR] [--device D] [-o out.ppm]
+ *   rayviewer scene.sdl [--passes N | --progressive P [--aa A]] [--dump PREFIX] [--assets DIR]
+ *             [--device D] [-o out.ppm]
  *
  * The reference's viewer renders the pixels one at a time in a shuffled order, no
  * antialiasing (camera_ray, rayviewer.c:137), and flips its window once per `width`
@@ -15,6 +16,15 @@
  * (rayviewer.c:62-75: floor(c * 256) clamped to 0..255, top row first).  A window
  * system would blit that surface; --dump writes it to PREFIX-<refresh>.ppm instead.
  * The finished frame does not depend on N or on the order of the passes.
+ *
+ * --progressive P refines by SAMPLES instead: antialiasing stays on (the scene's own
+ * aa_samples, or --aa A) and every pass renders a share of each pixel's samples
+ * (RTAMD_RENDER_PROGRESSIVE), so already the first refresh shows the whole picture,
+ * noisy, and every further one adds samples to all pixels.  Sample counts that divide
+ * 64 are taken in order, in P equal runs (P rounded down to a power of two): the
+ * library adds them in float in the reference's order.  Other counts are dealt out
+ * k, k+P, k+2P, ... in a shuffled order of the passes.  The last refresh is the batch
+ * driver's antialiased frame, bit for bit.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -59,9 +69,11 @@ int main(int argc, char **argv)
 	if (argc < 2)
 		return 1;                                 /* rayviewer.c:101-102 */
 	const char *sdl = argv[1], *assets = NULL, *out = "ray.ppm", *dump = NULL;
-	int passes = 16, device = 0;
+	int passes = 16, device = 0, progressive = 0, aa = -1;
 	for (int a = 2; a < argc; a++) {
 		if (!strcmp(argv[a], "--passes") && a + 1 < argc) passes = atoi(argv[++a]);
+		else if (!strcmp(argv[a], "--progressive") && a + 1 < argc) { progressive = 1; passes = atoi(argv[++a]); }
+		else if (!strcmp(argv[a], "--aa") && a + 1 < argc) aa = atoi(argv[++a]);
 		else if (!strcmp(argv[a], "--dump") && a + 1 < argc) dump = argv[++a];
 		else if (!strcmp(argv[a], "--assets") && a + 1 < argc) assets = argv[++a];
 		else if (!strcmp(argv[a], "--device") && a + 1 < argc) device = atoi(argv[++a]);
@@ -76,7 +88,22 @@ int main(int argc, char **argv)
 	if (rtamd_sdl_load(sdl, assets, &blob, &blob_size))
 		return fail(rtamd_last_error());
 	rtamd_blob_header *h = blob;
-	h->antialiasing = 0;                          /* rayviewer.c:137: always camera_ray */
+	if (!progressive)
+		h->antialiasing = 0;                      /* rayviewer.c:137: always camera_ray */
+	else if (aa > 0) {
+		h->antialiasing = 1;
+		h->aa_samples = aa;
+	}
+	const int spp = h->antialiasing ? h->aa_samples * h->aa_samples : 1;
+	const int ordered = progressive && 64 % spp == 0;
+	if (progressive && passes > spp)
+		passes = spp;
+	if (ordered) {
+		int p2 = 1;
+		while (2 * p2 <= passes)
+			p2 *= 2;
+		passes = p2;
+	}
 	const int w = h->width, hh = h->height;
 	rtamd_scene *scene = NULL;
 	if (rtamd_init(device) || rtamd_scene_create(blob, blob_size, &scene))
@@ -104,10 +131,20 @@ int main(int argc, char **argv)
 	p.seed = 0x20071208;                          /* rayviewer.c:123 */
 	p.rng_mode = RTAMD_RNG_KEYED;
 	p.tile_w = p.tile_h = 32;
-	p.tile_stride = passes;
+	p.tile_stride = progressive ? 1 : passes;
 	const double t0 = now();
 	for (int i = 0; i < passes; i++) {
-		p.tile_first = order[i];
+		if (ordered) {
+			p.flags = RTAMD_RENDER_PROGRESSIVE | (i == 0 ? RTAMD_RENDER_RESTART : 0);
+			p.sample_count = spp / passes;
+			p.sample_first = i * p.sample_count;
+			p.sample_stride = 1;
+		} else if (progressive) {
+			p.flags = RTAMD_RENDER_PROGRESSIVE | (i == 0 ? RTAMD_RENDER_RESTART : 0);
+			p.sample_first = order[i];
+			p.sample_stride = passes;
+		} else
+			p.tile_first = order[i];
 		if (rtamd_render(scene, &p, d_colour, NULL, NULL, NULL))
 			return fail(rtamd_last_error());
 		/* the refresh (SDL_Flip, rayviewer.c:143-149) */

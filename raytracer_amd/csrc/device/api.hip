@@ -67,6 +67,8 @@ struct rtamd_scene {
 	bool glibc_powers_uploaded = false;
 	long long *d_accum = nullptr;
 	unsigned long long accum_slots = 0;
+	float *d_fsum = nullptr;                     // progressive frames: ordered float sums, float4 per pixel
+	unsigned long long fsum_slots = 0;
 	QueueItem *d_queue[3] = { nullptr, nullptr, nullptr };   // level 1; deeper levels alternate between the other two
 	unsigned queue_capacity = 0;
 	unsigned *d_qcount = nullptr;
@@ -78,6 +80,7 @@ struct rtamd_scene {
 	bool bounce_packets = false; // unsorted pass: queued rays walk as wave-wide packets (mirror-only scenes)
 	int device = -1;             // the device the scene's buffers live on
 	std::vector<double> mesh_build_seconds;
+	int progress_samples = 0;    // RTAMD_RENDER_PROGRESSIVE: samples per pixel summed in the accumulators
 	// RTAMD_RENDER_TIME_KERNELS: event pairs around primary launches, read by rtamd_scene_take_kernel_times
 	std::vector<hipEvent_t> deferred_events;
 	std::vector<char> mesh_built_on_device;   // per mesh: its tree is the GPU-built one
@@ -217,6 +220,7 @@ extern "C" int rtamd_scene_destroy(rtamd_scene *sc)
 	if (sc->d_glibc_powers) (void)hipFree(sc->d_glibc_powers);
 	if (sc->d_glibc_window) (void)hipFree(sc->d_glibc_window);
 	if (sc->d_accum) (void)hipFree(sc->d_accum);
+	if (sc->d_fsum) (void)hipFree(sc->d_fsum);
 	for (QueueItem *q : sc->d_queue)
 		if (q)
 			(void)hipFree(q);
@@ -247,6 +251,10 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	d.reflection_samples = h.reflection_samples;
 	d.max_reflections = h.max_reflections;
 	d.spp = h.antialiasing ? h.aa_samples * h.aa_samples : 1;
+	d.sub_first = 0;
+	d.sub_stride = 1;
+	d.sub_count = d.spp;
+	d.resolve_samples = d.spp;
 	std::memcpy(d.cam_pos, h.cam_position, sizeof d.cam_pos);
 	std::memcpy(d.cam_u, h.cam_u, sizeof d.cam_u);
 	std::memcpy(d.cam_v, h.cam_v, sizeof d.cam_v);
@@ -816,6 +824,7 @@ static int ensure_glibc_buffers(rtamd_scene *sc, uint32_t seed, unsigned long lo
 // rtamd_render_noalloc carves them out of this device's static scratch array.
 struct RenderWork {
 	long long *accum;            // 3 x int64 per owned pixel, or null (direct frames)
+	float *fsum;                 // progressive frames whose samples share a wave: float4 per pixel, else null
 	QueueItem *queue[3];         // [0]: rays of depth 1; [1], [2]: deeper levels, alternating
 	unsigned queue_capacity;
 	unsigned *qcount;            // 128 counters, one per bounce level
@@ -876,13 +885,27 @@ static int take_sticky_overflow(rtamd_scene *sc)
 // run of owned tiles the call's window can touch).  w.accum holds one slot per pixel
 // of that run; the kernels index accumulators by position in the whole sequence, so
 // they get the pointer moved back by the run's start.
+static unsigned long long pixels_of(unsigned long long lo, unsigned long long hi) { return hi - lo; }
+
 static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const RenderWork &w, bool direct,
 		unsigned long long pix_lo, unsigned long long pix_hi, void *d_colour, void *d_hits,
 		rtamd_render_stats *stats, hipStream_t stream)
 {
-	const DevScene &dev = sc->dev;
+	DevScene dev = sc->dev;
+	const bool progressive = (p.flags & RTAMD_RENDER_PROGRESSIVE) != 0;
+	if (progressive) {
+		dev.sub_stride = p.sample_stride > 0 ? p.sample_stride : 1;
+		dev.sub_first = p.sample_first;
+		dev.sub_count = (dev.spp - dev.sub_first + dev.sub_stride - 1) / dev.sub_stride;
+		if (p.sample_count > 0 && p.sample_count < dev.sub_count)
+			dev.sub_count = p.sample_count;
+		sc->progress_samples += dev.sub_count;
+		dev.resolve_samples = sc->progress_samples;
+		if (w.fsum && (p.flags & RTAMD_RENDER_RESTART))
+			HIP_TRY(hipMemsetAsync(w.fsum, 0, pixels_of(pix_lo, pix_hi) * 4 * sizeof(float), stream));
+	}
 	const unsigned long long pixels = pix_hi - pix_lo;
-	const unsigned long long sample_lo = pix_lo * (unsigned)dev.spp, samples = pix_hi * (unsigned)dev.spp;
+	const unsigned long long sample_lo = pix_lo * (unsigned)dev.sub_count, samples = pix_hi * (unsigned)dev.sub_count;
 	long long *const accum = w.accum ? w.accum - 3 * (long long)pix_lo : nullptr;
 	const unsigned long long fan = vertex_fan(sc);
 	unsigned long long chunk = samples - sample_lo;
@@ -934,7 +957,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 		HIP_TRY(hipEventCreate(&ev.whole[1]));
 		HIP_TRY(hipEventRecord(ev.whole[0], stream));
 	}
-	if (!direct)
+	if (!direct && (!progressive || (p.flags & RTAMD_RENDER_RESTART)))
 		HIP_TRY(hipMemsetAsync(w.accum, 0, pixels * 3 * sizeof(long long), stream));
 	HIP_TRY(hipMemsetAsync(w.counters, 0, sizeof(DevCounters) * RT_COUNTER_COPIES, stream));
 
@@ -979,7 +1002,7 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 				HIP_TRY(hipEventRecord(e, stream));
 			}
 			HIP_TRY(rt_launch_primary(dev, p, first, count, table, accum,
-					direct ? static_cast<float *>(d_colour) : nullptr, static_cast<rtamd_hit_record *>(d_hits),
+					direct ? static_cast<float *>(d_colour) : nullptr, w.fsum, static_cast<rtamd_hit_record *>(d_hits),
 					levels ? w.queue[0] : nullptr, levels ? w.qcount : nullptr, kernel_capacity, w.counters, stream));
 			if (timed || deferred) {
 				hipEvent_t e = nullptr;
@@ -1018,7 +1041,8 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 	}
 	HIP_TRY(rt_launch_collect_stats(w.counters, stream));
 	if (!direct)
-		HIP_TRY(rt_launch_resolve(dev, p, pix_lo, pixels, accum, static_cast<float *>(d_colour), w.counters,
+		HIP_TRY(rt_launch_resolve(dev, p, pix_lo, pixels, (w.fsum && !dev.any_reflective) ? nullptr : accum, w.fsum,
+				static_cast<float *>(d_colour), w.counters,
 				sc->d_overflow, stream));
 
 	if (stats) {
@@ -1107,6 +1131,39 @@ static int render_prepare(rtamd_scene *sc, const rtamd_render_params *params, vo
 	// Without reflections, and with all samples of a pixel inside one wave, the
 	// primary kernel writes finished pixels itself: no accumulators, no resolve.
 	*direct = !sc->dev.any_reflective && 64 % sc->dev.spp == 0;
+	if (p->flags & RTAMD_RENDER_PROGRESSIVE) {
+		const bool whole = (p->x0 == 0 && p->y0 == 0 && p->x1 == 0 && p->y1 == 0) ||
+				(p->x0 == 0 && p->y0 == 0 && p->x1 == sc->dev.width && p->y1 == sc->dev.height);
+		const int stride = p->sample_stride > 0 ? p->sample_stride : 1;
+		if (!whole || p->tile_stride != 1 || d_hits) {
+			rtamd_set_error("progressive renders take the whole frame, all tiles, no hit records");
+			return RTAMD_ERR_ARG;
+		}
+		if (p->flags & RTAMD_RENDER_RESTART)
+			sc->progress_samples = 0;
+		const int spp = sc->dev.spp;
+		if (p->sample_first < 0 || p->sample_first >= spp || stride > spp || p->sample_count < 0) {
+			rtamd_set_error("bad sample subset: first %d stride %d count %d of %d samples per pixel", p->sample_first,
+					p->sample_stride, p->sample_count, spp);
+			return RTAMD_ERR_ARG;
+		}
+		if (64 % spp == 0) {
+			// a pixel's samples are added in float, in order: the passes must follow that order
+			int count = (spp - p->sample_first + stride - 1) / stride;
+			if (p->sample_count > 0 && p->sample_count < count)
+				count = p->sample_count;
+			if (stride != 1 || p->sample_first != sc->progress_samples || 64 % count != 0) {
+				rtamd_set_error("with %d samples per pixel a progressive frame takes its samples in order: "
+						"sample_stride 1, sample_first = samples rendered so far (%d), sample_count a divisor of 64",
+						spp, sc->progress_samples);
+				return RTAMD_ERR_ARG;
+			}
+		}
+		*direct = false;       // the sums live in the scene's buffers from pass to pass
+	} else if (p->sample_first != 0 || p->sample_stride > 1) {
+		rtamd_set_error("a sample subset needs RTAMD_RENDER_PROGRESSIVE");
+		return RTAMD_ERR_ARG;
+	}
 	return 0;
 }
 
@@ -1204,7 +1261,25 @@ extern "C" int rtamd_render(rtamd_scene *sc, const rtamd_render_params *params, 
 			}
 		}
 	}
+	float *fsum = nullptr;
+	if ((p.flags & RTAMD_RENDER_PROGRESSIVE) && 64 % dev.spp == 0) {
+		if (sc->fsum_slots < pixels) {
+			if (sc->d_fsum) {
+				HIP_TRY(hipStreamSynchronize(stream));
+				(void)hipFree(sc->d_fsum);
+				sc->d_fsum = nullptr;
+				sc->fsum_slots = 0;
+			}
+			void *ptr = nullptr;
+			HIP_TRY(hipMalloc(&ptr, pixels * 4 * sizeof(float) + 16));
+			HIP_TRY(hipMemsetAsync(ptr, 0, pixels * 4 * sizeof(float), stream));
+			sc->d_fsum = static_cast<float *>(ptr);
+			sc->fsum_slots = pixels;
+		}
+		fsum = sc->d_fsum;
+	}
 	RenderWork w;
+	w.fsum = fsum;
 	w.accum = direct ? nullptr : sc->d_accum;
 	w.queue[0] = sc->d_queue[0];
 	w.queue[1] = sc->d_queue[1];
@@ -1272,6 +1347,11 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	if (rc)
 		return rc;
 	const unsigned long long pixels = pix_hi - pix_lo;
+	if (p.flags & RTAMD_RENDER_PROGRESSIVE) {
+		rtamd_set_error("rtamd_render_noalloc: progressive frames keep their sums in the scene's own buffers; "
+				"use rtamd_render");
+		return RTAMD_ERR_ARG;
+	}
 	if (!pixels)
 		return 0;          // an owner without tiles in the window: nothing to render
 	unsigned char *base = (sc->device >= 0 && sc->device < MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;

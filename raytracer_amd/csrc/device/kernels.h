@@ -15,7 +15,7 @@ hipError_t rt_launch_glibc_fill(const GlibcJump &start, const uint32_t *powers, 
 
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, GlibcTable glibc_table,
-		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
+		long long *accum, float *direct_out, float *fsum, rtamd_hit_record *hits, QueueItem *queue_out,
 		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream);
 /* Scratch of one bounce level of the coherent pass: per queue entry the nearest
  * hit; two buffers of (key, queue index) pairs for the radix sort of the hits; the
@@ -40,8 +40,8 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, lon
 		unsigned *queue_out_count, DevCounters *counters, const BounceWork &work, unsigned grid_blocks,
 		hipStream_t stream);
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
-		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
-		unsigned long long *overflow_out, hipStream_t stream);
+		unsigned long long pixel_count, const long long *accum, const float *fsum, float *colour,
+		DevCounters *counters, unsigned long long *overflow_out, hipStream_t stream);
 hipError_t rt_launch_collect_stats(DevCounters *counters, hipStream_t stream);
 hipError_t rt_launch_trace(const DevScene &sc, const double *rays, unsigned long long n,
 		rtamd_hit_record *hits, hipStream_t stream);

@@ -83,7 +83,7 @@ DEV unsigned slice_count(const QueueSlice &q)
 template <int WAVES>
 __global__ void __launch_bounds__(RT_BLOCK, WAVES)
 k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned long long sample_count,
-		int rng_mode, uint32_t seed, GlibcTable glibc_table, long long *accum, float *direct_out,
+		int rng_mode, uint32_t seed, GlibcTable glibc_table, long long *accum, float *direct_out, float *fsum,
 		rtamd_hit_record *hits, QueueItem *queue_out, unsigned *queue_count, unsigned queue_capacity,
 		DevCounters *counters)
 {
@@ -102,7 +102,8 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 	unsigned long long sample = sample_first + local;
 	int px = 0, py = 0, k = 0;
 	uint32_t slot = 0;
-	bool active = local < sample_count && sample_to_pixel(tm, sc.spp, sample, px, py, k, slot);
+	bool active = local < sample_count && sample_to_pixel(tm, sc.sub_count, sample, px, py, k, slot);
+	k = sc.sub_first + sc.sub_stride * k;
 
 	uint32_t key = 0;
 	Ray ray;
@@ -130,7 +131,8 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		int qx = 0, qy = 0, qk = 0;
 		uint32_t qslot, qkey;
 		float ox, oy;
-		sample_to_pixel(tm, sc.spp, sample_first + (unsigned long long)blockIdx.x * RT_BLOCK + tid, qx, qy, qk, qslot);
+		sample_to_pixel(tm, sc.sub_count, sample_first + (unsigned long long)blockIdx.x * RT_BLOCK + tid, qx, qy, qk, qslot);
+		qk = sc.sub_first + sc.sub_stride * qk;
 		sample_offsets(sc, rng_mode, glibc_table, seed, qx, qy, qk, qkey, ox, oy);
 		return camera_ray(sc, qx, qy, ox, oy).d;
 	};
@@ -143,12 +145,30 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 		unsigned tid = threadIdx.x;
 		asm volatile("" : "+v"(tid));
 		const unsigned long long l2 = (unsigned long long)blockIdx.x * RT_BLOCK + tid;
-		tactive = l2 < sample_count && sample_to_pixel(tm, sc.spp, sample_first + l2, tx, ty, tk, tslot);
+		tactive = l2 < sample_count && sample_to_pixel(tm, sc.sub_count, sample_first + l2, tx, ty, tk, tslot);
 	}
 
 	TM_BEGIN(t_tail);
 	const unsigned lane = lane_id();
-	if (64 % sc.spp == 0) {
+	if (64 % sc.spp == 0 && fsum) {
+		// Progressive frame: this call's samples of a pixel (a run of sub_count lanes)
+		// continue the pixel's float sum where the pass before left it, in sample order.
+		const unsigned run = (unsigned)sc.sub_count;
+		const unsigned base = lane - lane % run;
+		float4 *cell = reinterpret_cast<float4 *>(fsum) + tslot;
+		float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+		if (tactive) {
+			const float4 before = *cell;      // zero at the start of a frame
+			ar = before.x; ag = before.y; ab = before.z;
+		}
+		for (unsigned j = 0; j < run; j++) {
+			ar += __shfl(total.r, (int)(base + j), 64);
+			ag += __shfl(total.g, (int)(base + j), 64);
+			ab += __shfl(total.b, (int)(base + j), 64);
+		}
+		if (tactive && lane == base)
+			*cell = make_float4(ar, ag, ab, 0.0f);
+	} else if (64 % sc.spp == 0) {
 		// All samples of a pixel sit in consecutive lanes of this wave: add them in
 		// the reference's order, ((c0 + c1) + c2) + ... in float (raytracer.c:41-45).
 		const unsigned spp = (unsigned)sc.spp;
@@ -193,8 +213,9 @@ k_primary(DevScene sc, TileMap tm, unsigned long long sample_first, unsigned lon
 			}
 		}
 	} else {
-		// Per-pixel sum in 2^-32 fixed point: integer adds commute, so the result does
-		// not depend on the order in which lanes, waves or later bounces arrive.
+		// Per-pixel sum in 2^-32 fixed point, every sample converted on its own: integer
+		// adds commute, so the result does not depend on the order in which lanes, waves,
+		// later bounces or the passes of a progressive frame arrive.
 		accumulate_runs(accum, tslot, total, tactive);
 	}
 	const u64 active_lanes = __builtin_amdgcn_ballot_w64(tactive), env_lanes = __builtin_amdgcn_ballot_w64(n_env != 0);
@@ -915,7 +936,8 @@ hipError_t rt_launch_glibc_fill(const GlibcJump &start, const uint32_t *powers, 
 // Accumulators -> the reference's float RGBA frame (raytracer.c:46,81): the
 // per-pixel sum is scaled by the float 1.0/aa^2 when antialiasing is on.
 __global__ void k_resolve(DevScene sc, TileMap tm, unsigned long long pixel_first, unsigned long long pixel_count,
-		const long long *accum, float *colour, const DevCounters *counters, unsigned long long *overflow_out)
+		const long long *accum, const float *fsum, float *colour, const DevCounters *counters,
+		unsigned long long *overflow_out)
 {
 	unsigned long long local = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
 	// the last kernel of a reflective frame leaves a queue overflow where the host
@@ -929,12 +951,24 @@ __global__ void k_resolve(DevScene sc, TileMap tm, unsigned long long pixel_firs
 	uint32_t slot;
 	if (!sample_to_pixel(tm, 1, pix, px, py, k, slot))
 		return;
-	const long long *a = accum + 3ull * slot;
-	float r = (float)((double)a[0] / RT_FIX_SCALE);
-	float g = (float)((double)a[1] / RT_FIX_SCALE);
-	float b = (float)((double)a[2] / RT_FIX_SCALE);
+	// a progressive frame keeps the ordered float sum of the directly lit part beside
+	// the fixed-point sums of what the bounces add (the single call adds the former to
+	// the latter as one fixed-point value: the same total)
+	float r = 0.0f, g = 0.0f, b = 0.0f;
+	long long fix[3] = { 0, 0, 0 };
+	if (fsum) {
+		const float4 f = reinterpret_cast<const float4 *>(fsum)[slot];
+		r = f.x; g = f.y; b = f.z;
+		fix[0] = to_fixed(f.x); fix[1] = to_fixed(f.y); fix[2] = to_fixed(f.z);
+	}
+	if (accum) {
+		const long long *a = accum + 3ull * slot;
+		r = (float)((double)(a[0] + fix[0]) / RT_FIX_SCALE);
+		g = (float)((double)(a[1] + fix[1]) / RT_FIX_SCALE);
+		b = (float)((double)(a[2] + fix[2]) / RT_FIX_SCALE);
+	}
 	if (sc.antialiasing) {
-		float s = (float)(1.0 / (double)sc.spp);
+		float s = (float)(1.0 / (double)sc.resolve_samples);
 		r = s * r; g = s * g; b = s * b;
 	}
 	float4 out = { r, g, b, 0.0f };
@@ -1101,7 +1135,7 @@ void rt_window_tile_rows(int width, int height, const rtamd_render_params &p, in
 
 hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 		unsigned long long sample_first, unsigned long long sample_count, GlibcTable glibc_table,
-		long long *accum, float *direct_out, rtamd_hit_record *hits, QueueItem *queue_out,
+		long long *accum, float *direct_out, float *fsum, rtamd_hit_record *hits, QueueItem *queue_out,
 		unsigned *queue_count, unsigned queue_capacity, DevCounters *counters, hipStream_t stream)
 {
 	if (!sample_count)
@@ -1110,11 +1144,11 @@ hipError_t rt_launch_primary(const DevScene &sc, const rtamd_render_params &p,
 	unsigned long long blocks = (sample_count + RT_BLOCK - 1) / RT_BLOCK;
 	if (sc.any_area_light && sc.shadow_rays_per_hit >= RT_LONG_SHADOW_LOOPS)
 		hipLaunchKernelGGL(k_primary<RT_MIN_WAVES_LONG>, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm,
-				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out,
+				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, fsum, hits, queue_out,
 				queue_count, queue_capacity, counters);
 	else
 		hipLaunchKernelGGL(k_primary<RT_MIN_WAVES>, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, stream, sc, tm,
-				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, hits, queue_out,
+				sample_first, sample_count, p.rng_mode, p.seed, glibc_table, accum, direct_out, fsum, hits, queue_out,
 				queue_count, queue_capacity, counters);
 	return hipGetLastError();
 }
@@ -1186,15 +1220,15 @@ hipError_t rt_launch_bounce_sorted(const DevScene &sc, const QueueSlice &in, lon
 }
 
 hipError_t rt_launch_resolve(const DevScene &sc, const rtamd_render_params &p, unsigned long long pixel_first,
-		unsigned long long pixel_count, const long long *accum, float *colour, DevCounters *counters,
-		unsigned long long *overflow_out, hipStream_t stream)
+		unsigned long long pixel_count, const long long *accum, const float *fsum, float *colour,
+		DevCounters *counters, unsigned long long *overflow_out, hipStream_t stream)
 {
 	if (!pixel_count)
 		return hipSuccess;
 	TileMap tm = make_tile_map(sc.width, sc.height, p);
 	unsigned long long blocks = (pixel_count + 255) / 256;
 	hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, stream, sc, tm, pixel_first, pixel_count,
-			accum, colour, counters, overflow_out);
+			accum, fsum, colour, counters, overflow_out);
 	return hipGetLastError();
 }
 

@@ -106,6 +106,11 @@ struct DevScene {
 	int32_t num_lights, num_surfaces, has_cubemap, any_reflective;
 	int32_t any_area_light;
 	int32_t shadow_rays_per_hit; /* point lights + shadow_samples^2 per area light */
+	/* the samples of a pixel one call renders: sub_count of them, numbered sub_first +
+	 * sub_stride * i (all spp of them: 0, 1, spp); resolve_samples = samples summed in
+	 * the accumulators when the frame is written (spp unless the frame is refined
+	 * progressively) */
+	int32_t sub_first, sub_stride, sub_count, resolve_samples;
 	const DevLight *lights;
 	const DevSurface *surfaces;
 	const DevMaterial *materials;

@@ -28,7 +28,7 @@ def init(device=0):
 
 
 def make_params(seed=DEFAULT_SEED, rng_mode=_abi.RNG_KEYED, tile=(32, 32), tile_first=0,
-                tile_stride=1, window=None, flags=0):
+                tile_stride=1, window=None, flags=0, sample_first=0, sample_stride=0, sample_count=0):
     p = _abi.RenderParams()
     p.seed = seed
     p.rng_mode = rng_mode
@@ -38,6 +38,7 @@ def make_params(seed=DEFAULT_SEED, rng_mode=_abi.RNG_KEYED, tile=(32, 32), tile_
     if window is not None:
         p.x0, p.y0, p.x1, p.y1 = window
     p.flags = flags
+    p.sample_first, p.sample_stride, p.sample_count = sample_first, sample_stride, sample_count
     return p
 
 

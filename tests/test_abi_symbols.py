@@ -32,7 +32,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_abi.Surface) == 16 + 48 + 8 + 256 + 24
     assert C.sizeof(_abi.Mesh) == 48
     assert C.sizeof(_abi.Cubemap) == 96
-    assert C.sizeof(_abi.RenderParams) == 48
+    assert C.sizeof(_abi.RenderParams) == 56
 
 
 def test_device_entry_points_fail_loudly_without_init():

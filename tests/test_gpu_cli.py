@@ -142,3 +142,47 @@ def test_progressive_viewer_fills_in_and_ends_on_the_batch_frame(tmp_path):
         filled = [int((read_ppm(os.path.join(str(tmp_path), f"v{passes}-{i:03d}.ppm")).sum(axis=2) > 0).sum())
                   for i in range(passes)]
         assert all(b > a for a, b in zip(filled, filled[1:])) and filled[-1] > 0.9 * batch.shape[0] * batch.shape[1]
+
+
+def test_viewer_refines_by_samples_and_ends_on_the_batch_frame(tmp_path):
+    """rayviewer --progressive: every pass adds a subset of each pixel's samples; the first
+    refresh already covers the whole picture, the error against the finished frame falls
+    from refresh to refresh, and the frame left in ray.ppm is the batch driver's
+    antialiased frame byte for byte (7-reflections: per-pixel sums are fixed point).  A
+    window of that batch frame is compared with the CPU checker."""
+    import numpy as np
+    import raytracer_amd as ra
+    import oracle_lib
+    viewer = os.path.join(ROOT, "raytracer_amd", "csrc", "rayviewer")
+    scene = os.path.join(ASSETS, "7-reflections.sdl")
+    size = ["--width", "160", "--height", "120"]
+    r = subprocess.run([CLI, scene, "--assets", ASSETS, "--aa", "4", "--rng", "keyed", "-o", "batch.ppm"] + size,
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout
+    batch = read_ppm(os.path.join(str(tmp_path), "batch.ppm")).astype(int)
+    # the batch frame itself against the checker, on a window
+    blob = ra.load_sdl(scene).with_config(width=160, height=120, antialiasing=1, aa_samples=4)
+    win = (60, 40, 100, 70)
+    colour, _, _ = oracle_lib.OracleScene(blob).render(rng_mode=1, window=win, threads=8)
+    want = ra.quantise_rgb8(colour).astype(int)[120 - win[3]:120 - win[1], win[0]:win[2]]
+    got = batch[120 - win[3]:120 - win[1], win[0]:win[2]]
+    assert (np.abs(got - want) <= 1).all(axis=2).mean() >= 0.999
+    assert want.max() > 30
+    # the viewer needs the same frame size: a scene file with that <Config>
+    text = open(scene).read().replace('width =  "640"', 'width="160"').replace('height = "640"', 'height="120"')
+    small = os.path.join(str(tmp_path), "small.sdl")
+    with open(small, "w") as f:
+        f.write(text)
+    for passes in (1, 4, 16):
+        r = subprocess.run([viewer, small, "--assets", ASSETS, "--progressive", str(passes), "--aa", "4",
+                            "--dump", f"p{passes}"], cwd=str(tmp_path), capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stdout
+        assert np.array_equal(read_ppm(os.path.join(str(tmp_path), "ray.ppm")).astype(int), batch)
+        shots = [read_ppm(os.path.join(str(tmp_path), f"p{passes}-{i:03d}.ppm")).astype(int) for i in range(passes)]
+        # every refresh is a whole picture (the floor and the teapot are lit everywhere they are in the end)
+        lit = batch.sum(axis=2) > 24
+        for s in shots:
+            assert (s.sum(axis=2)[lit] > 0).mean() > 0.99
+        if passes > 1:
+            err = [np.abs(s - shots[-1]).mean() for s in shots]
+            assert err[0] > err[len(err) // 2] > err[-1] == 0
