@@ -852,6 +852,10 @@ k_collect_stats(DevCounters *counters)
 		if (g_stat_walk[i])
 			printf("walk %s steps<2^%d %llu\n", i & 1 ? "occluded" : "free", i / 2, g_stat_walk[i]);
 		g_stat_walk[i] = 0;
+		if (i < 8 && g_stat_list[i])
+			printf("list %d %llu\n", i, g_stat_list[i]);
+		if (i < 8)
+			g_stat_list[i] = 0;
 	}
 #endif
 #ifdef RT_TIMING

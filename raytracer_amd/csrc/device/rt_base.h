@@ -58,6 +58,9 @@ __device__ unsigned long long g_stat_nodes, g_stat_tris;
 __device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
 // wave-level event counts: see the EV_ names
 __device__ unsigned long long g_stat_ev[32];
+// list walks: [0] walks, [1] listed leaves, [2] leaves some lane's ray enters, [3] the most leaves one
+// lane's ray enters (summed over walks), [4] leaves entered summed over lanes, [5] lanes in the walks
+__device__ unsigned long long g_stat_list[8];
 // per-lane any-hit walks by length: [2k] unoccluded, [2k + 1] occluded, k = bit length of the step count
 __device__ unsigned long long g_stat_walk[32];
 enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH_WALK_PRIMARY, EV_MESH_WALK_SHADOW,

@@ -196,12 +196,15 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 	const double dnear = (double)tnear, dfar = (double)tfar;
 	const float wlo = window_lo(tnear), whi = window_hi(tfar);
 	bool found = false;
+	RT_STAT(unsigned st_mine = 0; unsigned st_union = 0);
+	RT_STAT(const unsigned st_lanes = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
 	for (int c = 0; c < count; c++) {
 		const ShaftEntry e = list[c];
 		RT_EV(EV_LIST_BOX);
 		float tn;
 		const bool h = packet_box_hit(pr, e.lox, e.loy, e.loz, e.hix, e.hiy, e.hiz, tnear, tfar, tn) && !found;
 		u64 actm = __builtin_amdgcn_ballot_w64(h);
+		RT_STAT(st_mine += h ? 1u : 0u; st_union += actm ? 1u : 0u);
 		if (actm == 0)
 			continue;
 		const int v = ~__builtin_amdgcn_readfirstlane(e.ref);
@@ -222,6 +225,23 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 		if (__builtin_amdgcn_ballot_w64(!found) == 0)
 			break;
 	}
+#ifdef RT_TRAVERSAL_STATS
+	{
+		unsigned mx = st_mine, sm = st_mine;
+		for (int off = 32; off > 0; off >>= 1) {
+			mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+			sm += (unsigned)__shfl_xor((int)sm, off, 64);
+		}
+		if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+			atomicAdd(&g_stat_list[0], 1ull);
+			atomicAdd(&g_stat_list[1], (unsigned long long)count);
+			atomicAdd(&g_stat_list[2], (unsigned long long)st_union);
+			atomicAdd(&g_stat_list[3], (unsigned long long)mx);
+			atomicAdd(&g_stat_list[4], (unsigned long long)sm);
+			atomicAdd(&g_stat_list[5], (unsigned long long)st_lanes);
+		}
+	}
+#endif
 	return found;
 }
 
