@@ -184,28 +184,32 @@ def test_noalloc_through_the_per_lane_sorted_kernel(render, monkeypatch):
     dev.close()
 
 
-def test_frame_large_enough_for_the_default_dispatch(render, monkeypatch):
-    """8-glossy at 128 x 128 x 64 spp: about 0.3 M rays of depth 1 and eight times as many of
-    depth 2 (measured: 2.8 M secondary rays), all in the first slice of the depth-1 queue,
-    so the default dispatch itself sends these levels to k_bounce_shade (at least 2^18
-    hits) and the thin deeper levels to k_bounce_shade_small.  The whole frame is rendered; a window of it is compared with
-    the checker, and the whole frame with the unsorted pass, bit for bit."""
-    blob = ra.load_sdl(scene_path("8-glossy")).with_config(width=128, height=128, antialiasing=1, aa_samples=8)
+@pytest.mark.parametrize("name,least_secondary", [("8-glossy", 10 << 21), ("7-reflections", 1 << 21)])
+def test_frame_large_enough_for_the_default_dispatch(render, monkeypatch, name, least_secondary):
+    """The reflective benchmark scenes at their full 640 x 640 with 64 samples per pixel.  8-glossy:
+    one chunk, about 20 M rays of depth 1 and as many deeper ones, so the default dispatch
+    sends the dense levels to the packet form of k_bounce_shade (from 2^21 hits), the
+    middle ones to its per-lane form and the thin ones to k_bounce_shade_small, all after
+    the radix sort of the hits.  A window of the frame is compared with the checker, the
+    whole frame and the ray counts with the unsorted pass, bit for bit."""
+    blob = ra.load_sdl(scene_path(name)).with_config(antialiasing=1, aa_samples=8)
+    assert (blob.width, blob.height, blob.spp) == (640, 640, 64)
     p = render.make_params(rng_mode=_abi.RNG_KEYED)
     dev = scene_with(render, monkeypatch, blob, FORMS["default"])
     frame, _, st = dev.render(p)
-    assert st.rays_secondary > 9 * (1 << 18)
-    win = (48, 40, 80, 72)
+    assert st.rays_secondary > least_secondary
+    assert st.launches_primary == 1
+    win = (300, 250, 316, 262)
     colour, _, _ = oracle_lib.OracleScene(blob).render(rng_mode=_abi.RNG_KEYED, window=win, threads=8)
     g = frame.cpu().numpy()
     got, want = g[win[1]:win[3], win[0]:win[2]], colour[win[1]:win[3], win[0]:win[2]]
     assert want[..., :3].max() > 0.05
     assert rgb8_within(got, want, 1) >= 0.999
     assert np.abs(got[..., :3] - want[..., :3]).max() < 2e-5
+    dev.close()
     legacy = scene_with(render, monkeypatch, blob, FORMS["unsorted"])
     other, _, st2 = legacy.render(p)
     assert np.array_equal(other.cpu().numpy().view(np.uint32), g.view(np.uint32))
     assert (st.rays_primary, st.rays_shadow, st.rays_secondary, st.env_lookups) == (
         st2.rays_primary, st2.rays_shadow, st2.rays_secondary, st2.env_lookups)
-    dev.close()
     legacy.close()
