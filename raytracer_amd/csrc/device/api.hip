@@ -1354,6 +1354,7 @@ extern "C" int rtamd_render_noalloc(rtamd_scene *sc, const rtamd_render_params *
 	}
 	if (!pixels)
 		return 0;          // an owner without tiles in the window: nothing to render
+	p.flags &= ~RTAMD_RENDER_TIME_KERNELS;     // event pairs are host allocations: not from this entry point
 	unsigned char *base = (sc->device >= 0 && sc->device < MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;
 	if (!base) {
 		rtamd_set_error("rtamd_render_noalloc: no scratch address for device %d (rtamd_init not called?)",
