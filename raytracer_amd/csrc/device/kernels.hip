@@ -840,10 +840,15 @@ k_collect_stats(DevCounters *counters)
 	counters->tri_tests = g_stat_tris;
 	g_stat_nodes = 0;
 	g_stat_tris = 0;
-	for (int i = 0; i < RT_SHAFT_CAP + 8; i++) {
+	for (int i = 0; i < RT_SHAFT_CAP + 16; i++) {
 		if (g_stat_shaft[i])
 			printf("shaft %d %llu\n", i, g_stat_shaft[i]);
 		g_stat_shaft[i] = 0;
+	}
+	for (int i = 32; i < 40; i++) {
+		if (g_stat_ev[i])
+			printf("event %d %llu\n", i, g_stat_ev[i]);
+		g_stat_ev[i] = 0;
 	}
 	for (int i = 0; i < 32; i++) {
 		if (g_stat_ev[i])

@@ -55,9 +55,9 @@ DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_
 __device__ unsigned long long g_stat_nodes, g_stat_tris;
 // per wave, light and surface: [0..CAP] leaves listed, [CAP+1] list overflow, [CAP+2] surface culled,
 // [CAP+3] surface touched but not listed (analytic shape, no free list), [CAP+4] nodes visited by shafts
-__device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 8];
+__device__ unsigned long long g_stat_shaft[RT_SHAFT_CAP + 16];
 // wave-level event counts: see the EV_ names
-__device__ unsigned long long g_stat_ev[32];
+__device__ unsigned long long g_stat_ev[40];
 // list walks: [0] walks, [1] listed leaves, [2] leaves some lane's ray enters, [3] the most leaves one
 // lane's ray enters (summed over walks), [4] leaves entered summed over lanes, [5] lanes in the walks
 __device__ unsigned long long g_stat_list[8];
@@ -67,11 +67,14 @@ enum { EV_BBOX_PRIMARY, EV_BBOX_SHADOW, EV_PRIM_PRIMARY, EV_PRIM_SHADOW, EV_MESH
 	EV_MESH_LIST_SHADOW, EV_LIST_BOX, EV_TRI_STAGE2, EV_TRI_EXACT, EV_SHADE, EV_SHADOW_RAYS,
 	// per-lane walks: walks started (per wave) and the lanes in them, loop iterations and the lanes in them
 	EV_LANE_WALKS, EV_LANE_WALK_LANES, EV_LANE_STEPS, EV_LANE_STEP_LANES,
-	EV_BOX_SIZE0 = 16 /* .. 31: largest extent of a wave's hit-point box, 0.001 * 2^k */ };
+	EV_BOX_SIZE0 = 16 /* .. 31: largest extent of a wave's hit-point box, 0.001 * 2^k */,
+	// light samples that add exactly nothing (lanes), and packets of samples all of that kind
+	EV_DARK = 32, EV_DARK_PACKETS };
 #define RT_EV_ADD(e, n) do { const unsigned long long n_ = (unsigned long long)(n); if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_ev[e], n_); } while (0)
 #define RT_EV(e) RT_EV_ADD(e, 1)
 #else
 #define RT_EV(e) do { } while (0)
+#define RT_EV_ADD(e, n) do { } while (0)
 #endif
 
 // Build option RT_TIMING=1|2: per-wave cycle counts per code region (1: the

@@ -79,6 +79,26 @@ DEV c3 spec_colour(CLight &light, CMaterial &mat, d3 first, d3 second, d3 normal
 	return cmul(lc3(mat.specular), light_col);
 }
 
+// A light sample that faces away from the light (no diffuse term) and whose specular
+// term underflows to zero adds exactly nothing to the sum, occluded or not
+// (shading.c:48-54 adds the two terms of an unoccluded sample; x + 0 = x in float, and the
+// sums start at +0).  Its shadow ray is counted but need not be walked: typically the
+// rays that would start on the far side of a body and cross all of it.
+#ifndef RT_SKIP_DARK
+#define RT_SKIP_DARK 1
+#endif
+DEV bool sample_is_dark(CLight &light, CMaterial &mat, d3 cam_dir, d3 light_dir, d3 normal)
+{
+#if RT_SKIP_DARK
+	if (vdot(light_dir, normal) > 0)
+		return false;
+	const c3 c = cadd(diff_colour(light, mat, light_dir, normal), spec_colour(light, mat, cam_dir, light_dir, normal));
+	return c.r == 0.0f && c.g == 0.0f && c.b == 0.0f;
+#else
+	return false;
+#endif
+}
+
 // ---- wave helpers ------------------------------------------------------------
 
 
@@ -244,6 +264,8 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 					const Ray shadow = shadow_ray_towards(position, light_sample_point(sc, light, area, n, li, key, j), light_dir);
 					n_shadow++;
 					Best dummy;
+					if (sample_is_dark(light, mat, cam_dir, light_dir, normal))
+						continue;
 					if (trace<true, false>(sc, shadow, lane_stack, dummy, shaft_none()))
 						continue;
 					light_total = cadd(light_total, cadd(diff_colour(light, mat, light_dir, normal),
@@ -281,7 +303,9 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 					TM_END(TM_LIGHT_SETUP, t_gen);
 					Best dummy;
 					TM_BEGIN(t_tr);
-					const bool occluded = trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none());
+					bool occluded = true;
+					if (!sample_is_dark(light, mat, hc, light_dir, hn))
+						occluded = trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none());
 					TM_END(TM_TRACE_SHADOW, t_tr);
 					TM_BEGIN(t_sh);
 					if (!occluded)
@@ -329,7 +353,7 @@ DEV c3 lights_transposed(const ShadeIO &io, bool lit, d3 position, d3 normal, d3
 					d3 light_dir;
 					const Ray shadow = shadow_ray_towards(hp, light_sample_point(sc, light, area, n, li, hk, j), light_dir);
 					Best dummy;
-					if (!trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none()))
+					if (!sample_is_dark(light, mat, hc, light_dir, hn) && !trace<true, true>(sc, shadow, io.wave_stack, dummy, shaft_none()))
 						c = cadd(diff_colour(light, mat, light_dir, hn), spec_colour(light, mat, hc, light_dir, hn));
 				}
 				const int cnt = m - base < 64 ? m - base : 64;
@@ -410,20 +434,55 @@ DEV c3 shade_hit(const ShadeIO &io, bool lit, int surface, d3 position, d3 norma
 			const int n = area ? sc.shadow_samples : 1;
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
 			ShaftState shaft_state = shaft_none();
-			const bool use_shaft = shafts && area && n >= 2;
-			if (use_shaft) {
+			const int m = n * n;
+			int j = 0;
+#if RT_SKIP_DARK
+			// A wave that lies wholly on the far side of a body: while every lane's sample adds
+			// exactly nothing there is nothing to walk, and if that holds to the end no shaft is
+			// needed either.  Looked for only when the light's corner is behind every lane's
+			// surface; any other wave goes straight to its shaft.
+			if (__builtin_amdgcn_ballot_w64(vdot(vsub(ld3(light.position), position), normal) > 0) == 0) {
+				for (; j < m; j++) {
+					const d3 light_dir = vnorm(vsub(light_sample_point(sc, light, area, n, li, key, j), position));
+					if (__builtin_amdgcn_ballot_w64(!sample_is_dark(light, *mat, cam_dir, light_dir, normal)) != 0)
+						break;
+					n_shadow++;
+					RT_EV(EV_SHADOW_RAYS);
+					RT_EV(EV_DARK_PACKETS);
+					RT_EV_ADD(EV_DARK, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+				}
+			}
+#endif
+			if (shafts && area && n >= 2 && j < m) {
 				TM_BEGIN(t_shaft);
+#ifdef RT_TRAVERSAL_STATS
+				const u64 lit_mask = __builtin_amdgcn_ballot_w64(lit);
+				const int first_surface = __builtin_amdgcn_readlane(surface, __builtin_ctzll(lit_mask | (1ull << 63)));
+				const int stat_tag = (__builtin_amdgcn_ballot_w64(lit && surface != first_surface) != 0 ? 1 : 0) + (depth > 0 ? 2 : 0)
+					+ (__builtin_popcountll(lit_mask) < 32 ? 4 : 0);
+				shaft_state = shaft_build(sc, light, n, olo, ohi, stack, io.shaft_lists, stat_tag);
+#else
 				shaft_state = shaft_build(sc, light, n, olo, ohi, stack, io.shaft_lists);
+#endif
 				TM_END(TM_SHAFT, t_shaft);
 			}
-			for (int j = 0; j < n * n; j++) {
+			for (; j < m; j++) {
 				TM_BEGIN(t_lsetup);
 				d3 light_dir;
 				const Ray shadow = shadow_ray_towards(position, light_sample_point(sc, light, area, n, li, key, j), light_dir);
 				n_shadow++;
 				RT_EV(EV_SHADOW_RAYS);
 				Best dummy;
+				const bool dark = sample_is_dark(light, *mat, cam_dir, light_dir, normal);
 				TM_END(TM_LIGHT_SETUP, t_lsetup);
+#ifdef RT_TRAVERSAL_STATS
+				if (__builtin_amdgcn_ballot_w64(!dark) == 0)
+					RT_EV(EV_DARK_PACKETS);
+#endif
+				if (dark) {
+					RT_EV_ADD(EV_DARK, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+					continue;
+				}
 				TM_BEGIN(t_shadow);
 				const bool occluded = trace<true, PACKET>(sc, shadow, stack, dummy, shaft_state);
 				TM_END(TM_TRACE_SHADOW, t_shadow);

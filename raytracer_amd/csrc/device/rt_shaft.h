@@ -125,65 +125,131 @@ DEV void shaft_to_model(CSurface &s, f3 c, f3 r, f3 &cm, f3 &rm)
 	rm.z = __builtin_fabsf(m20) * bx + __builtin_fabsf(m21) * by + __builtin_fabsf(m22) * bz + k * __builtin_fabsf(m23);
 }
 
-// Collects the leaves of a mesh whose box the shaft touches.  Everything here
-// is wave-uniform.  Returns the number of leaves, or -1 when there are more than
-// `cap` (or the mesh is a single leaf): the caller then walks the BVH.
-DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int *wstack_i, ShaftEntry *out, int cap)
+// Collects the leaves of a mesh whose box the shaft touches.  Returns the number of
+// leaves, or -1 when there are more than `cap` (or the mesh is a single leaf): the
+// caller then walks the BVH.
+//
+// The descent starts depth first with everything wave-uniform (scalar node fetches, one
+// node per round): the thin shaft of a pixel on a floor is done after some 15 nodes.  A
+// shaft that is not done after RT_SHAFT_SERIAL_VISITS nodes is wide - a wave next to a
+// mesh touches hundreds - and the rest of its descent is breadth first and shared out
+// over the lanes: the pending nodes become a frontier in LDS, lane i tests the two
+// children of frontier node i (every lane holds the same shaft), and ballots with prefix
+// counts place the touched leaves in the list and the touched inner nodes in the next
+// frontier, so that a round takes a whole level of the tree.  A level of more than 64
+// touched nodes counts as an overflow.  The caller's lanes need not all be active: the
+// active ones share the work by rank.
+#ifndef RT_SHAFT_SERIAL_VISITS
+#define RT_SHAFT_SERIAL_VISITS 24
+#endif
+DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int *wstack, ShaftEntry *out, int cap)
 {
-	int4 *wstack = reinterpret_cast<int4 *>(wstack_i);
-	const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
-	const bool writer = lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+	const u64 exec = __builtin_amdgcn_ballot_w64(true);
+	const u64 below = (1ull << lane_id()) - 1ull;
+	const int rank = __builtin_popcountll(exec & below), lanes = __builtin_popcountll(exec);
+	const bool writer = rank == 0;
 	int ref = __builtin_amdgcn_readfirstlane(mesh.root);
 	if (ref < 0)
 		return -1;
-	int sp = 0, n = 0;
-	for (;;) {
-		RT_STAT(if (writer) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 4], 1ull));
-		const float4 q0 = cload(nodes, 4 * ref + 0), q1 = cload(nodes, 4 * ref + 1);
-		const float4 q2 = cload(nodes, 4 * ref + 2), q3 = cload(nodes, 4 * ref + 3);
-		const bool h0 = __builtin_amdgcn_ballot_w64(shaft_box(st, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y)) != 0;
-		const bool h1 = __builtin_amdgcn_ballot_w64(shaft_box(st, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w)) != 0;
-		const int c0 = as_i(q3.x), c1 = as_i(q3.y);
-		int next = 0;
-		bool have_next = false;
-		if (h0) {
-			if (c0 < 0) {
-				if (n == cap)
-					return -1;
+	int sp = 0, n = 0, nf = 0;
+	{
+		const const_f4 nodes = as_const(sc.nodes + mesh.node_first);
+		for (int visits = 0;; visits++) {
+			if (visits == RT_SHAFT_SERIAL_VISITS) {
+				// the pending nodes, wstack[0 .. sp) and `ref`, are the first frontier
 				if (writer)
-					out[n] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, c0, 0 };
-				n++;
-			} else {
-				next = c0;
-				have_next = true;
+					wstack[sp] = ref;
+				nf = sp + 1;
+				break;
 			}
-		}
-		if (h1) {
-			if (c1 < 0) {
-				if (n == cap)
-					return -1;
-				if (writer)
-					out[n] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c1, 0 };
-				n++;
-			} else if (have_next) {
-				if (sp == RT_MAX_STACK)
-					return -1;
-				if (writer)
-					wstack[sp] = make_int4(c1, 0, 0, 0);
-				sp++;
-			} else {
-				next = c1;
-				have_next = true;
+			RT_STAT(if (writer) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 4], 1ull));
+			const float4 q0 = cload(nodes, 4 * ref + 0), q1 = cload(nodes, 4 * ref + 1);
+			const float4 q2 = cload(nodes, 4 * ref + 2), q3 = cload(nodes, 4 * ref + 3);
+			const bool h0 = __builtin_amdgcn_ballot_w64(shaft_box(st, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y)) != 0;
+			const bool h1 = __builtin_amdgcn_ballot_w64(shaft_box(st, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w)) != 0;
+			const int c0 = as_i(q3.x), c1 = as_i(q3.y);
+			int next = 0;
+			bool have_next = false;
+			if (h0) {
+				if (c0 < 0) {
+					if (n == cap)
+						return -1;
+					if (writer)
+						out[n] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, c0, 0 };
+					n++;
+				} else {
+					next = c0;
+					have_next = true;
+				}
 			}
+			if (h1) {
+				if (c1 < 0) {
+					if (n == cap)
+						return -1;
+					if (writer)
+						out[n] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c1, 0 };
+					n++;
+				} else if (have_next) {
+					// (the serial part pushes at most once per visit: sp stays below 64)
+					if (writer)
+						wstack[sp] = c1;
+					sp++;
+				} else {
+					next = c1;
+					have_next = true;
+				}
+			}
+			if (!have_next) {
+				if (sp == 0)
+					return n;
+				sp--;
+				next = __builtin_amdgcn_readfirstlane(wstack[sp]);
+			}
+			ref = next;
 		}
-		if (!have_next) {
-			if (sp == 0)
-				return n;
-			sp--;
-			next = __builtin_amdgcn_readfirstlane(wstack[sp].x);
-		}
-		ref = next;
 	}
+	// two frontiers of 64 node references in the wave's stack area (128 ints)
+	const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes + mesh.node_first);
+	int *front = wstack, *next = wstack + 64;
+	while (nf > 0) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		int ni = 0;
+		for (int base = 0; base < nf; base += lanes) {
+			const bool active = base + rank < nf;
+			bool h0 = false, h1 = false;
+			int c0 = 0, c1 = 0;
+			float4 q0 = { 0, 0, 0, 0 }, q1 = q0, q2 = q0;
+			if (active) {
+				const int node = front[base + rank];
+				RT_STAT(atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 5], 1ull));
+				q0 = nodes[4 * node + 0]; q1 = nodes[4 * node + 1]; q2 = nodes[4 * node + 2];
+				const float4 q3 = nodes[4 * node + 3];
+				c0 = as_i(q3.x); c1 = as_i(q3.y);
+				h0 = shaft_box(st, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+				h1 = shaft_box(st, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+			}
+			const u64 l0 = __builtin_amdgcn_ballot_w64(h0 && c0 < 0), l1 = __builtin_amdgcn_ballot_w64(h1 && c1 < 0);
+			const u64 i0 = __builtin_amdgcn_ballot_w64(h0 && c0 >= 0), i1 = __builtin_amdgcn_ballot_w64(h1 && c1 >= 0);
+			const int nl0 = __builtin_popcountll(l0), nl = nl0 + __builtin_popcountll(l1);
+			const int ni0 = __builtin_popcountll(i0), nin = ni0 + __builtin_popcountll(i1);
+			if (n + nl > cap || ni + nin > 64)
+				return -1;
+			if (h0 && c0 < 0)
+				out[n + __builtin_popcountll(l0 & below)] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, c0, 0 };
+			if (h1 && c1 < 0)
+				out[n + nl0 + __builtin_popcountll(l1 & below)] = { q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c1, 0 };
+			if (h0 && c0 >= 0)
+				next[ni + __builtin_popcountll(i0 & below)] = c0;
+			if (h1 && c1 >= 0)
+				next[ni + ni0 + __builtin_popcountll(i1 & below)] = c1;
+			n += nl;
+			ni += nin;
+		}
+		nf = ni;
+		int *t = front; front = next; next = t;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	return n;
 }
 
 // Any-hit over a shaft's leaf list: the per-ray part of mesh_traverse_packet<true>
@@ -250,7 +316,7 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 // segments: origin = hit point + 1e-4 dir, end = origin + (float)|to_light| dir,
 // the light point = position + alpha edge1 + beta edge2 with alpha, beta in [0, 2 - 1/n].
 DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float olo[3], const float ohi[3],
-		int *wstack, ShaftEntry *lists)
+		int *wstack, ShaftEntry *lists, int stat_tag = 0)
 {
 	ShaftState ss;
 	ss.cull = 0;
@@ -309,6 +375,7 @@ DEV ShaftState shaft_build(const DevScene &sc, CLight &light, int n, const float
 		const int room = RT_SHAFT_POOL - used < 254 ? RT_SHAFT_POOL - used : 254;
 		const int n_leaves = shaft_collect(sc, in_const(sc.meshes)[s.mesh], model, wstack, lists + used, room);
 		RT_STAT(if (counter) atomicAdd(&g_stat_shaft[n_leaves >= 0 ? n_leaves : RT_SHAFT_CAP + 1], 1ull));
+		RT_STAT(if (counter && n_leaves < 0) atomicAdd(&g_stat_shaft[RT_SHAFT_CAP + 8 + stat_tag], 1ull));
 		if (n_leaves >= 0) {
 			used += n_leaves;
 			ss.counts = (ss.counts & ~(0xffu << (8 * my_slot))) | ((unsigned)n_leaves << (8 * my_slot));
