@@ -435,25 +435,7 @@ DEV c3 shade_hit(const ShadeIO &io, bool lit, int surface, d3 position, d3 norma
 			c3 light_total = { 0.0f, 0.0f, 0.0f };
 			ShaftState shaft_state = shaft_none();
 			const int m = n * n;
-			int j = 0;
-#if RT_SKIP_DARK
-			// A wave that lies wholly on the far side of a body: while every lane's sample adds
-			// exactly nothing there is nothing to walk, and if that holds to the end no shaft is
-			// needed either.  Looked for only when the light's corner is behind every lane's
-			// surface; any other wave goes straight to its shaft.
-			if (__builtin_amdgcn_ballot_w64(vdot(vsub(ld3(light.position), position), normal) > 0) == 0) {
-				for (; j < m; j++) {
-					const d3 light_dir = vnorm(vsub(light_sample_point(sc, light, area, n, li, key, j), position));
-					if (__builtin_amdgcn_ballot_w64(!sample_is_dark(light, *mat, cam_dir, light_dir, normal)) != 0)
-						break;
-					n_shadow++;
-					RT_EV(EV_SHADOW_RAYS);
-					RT_EV(EV_DARK_PACKETS);
-					RT_EV_ADD(EV_DARK, __builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
-				}
-			}
-#endif
-			if (shafts && area && n >= 2 && j < m) {
+			if (shafts && area && n >= 2) {
 				TM_BEGIN(t_shaft);
 #ifdef RT_TRAVERSAL_STATS
 				const u64 lit_mask = __builtin_amdgcn_ballot_w64(lit);
@@ -466,7 +448,7 @@ DEV c3 shade_hit(const ShadeIO &io, bool lit, int surface, d3 position, d3 norma
 #endif
 				TM_END(TM_SHAFT, t_shaft);
 			}
-			for (; j < m; j++) {
+			for (int j = 0; j < m; j++) {
 				TM_BEGIN(t_lsetup);
 				d3 light_dir;
 				const Ray shadow = shadow_ray_towards(position, light_sample_point(sc, light, area, n, li, key, j), light_dir);
