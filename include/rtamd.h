@@ -254,7 +254,9 @@ typedef struct rtamd_render_params {
 
 typedef struct rtamd_render_stats {
 	uint64_t rays_primary;          /* ray_intersect-equivalent queries, by kind */
-	uint64_t rays_shadow;
+	uint64_t rays_shadow;           /* shadow queries as shading.c:22-47 makes them; one whose two Phong
+	                                 * terms are exactly zero is counted, but answered without a walk
+	                                 * (it adds +0 whether occluded or not) */
 	uint64_t rays_secondary;
 	uint64_t env_lookups;
 	uint64_t queue_peak;            /* largest ray-queue population seen */

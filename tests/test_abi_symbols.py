@@ -24,6 +24,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), name
 
 
+def test_checking_build_of_the_library_exports_the_same():
+    """librtamd_walkall.so (every shadow ray walked; the GPU tests compare its frames with the
+    product's) is the same sources with one switch: same entry points."""
+    handle = C.CDLL(os.path.join(os.path.dirname(_abi.LIB_PATH), "librtamd_walkall.so"))
+    for name in declared_symbols():
+        assert hasattr(handle, name), name
+
+
 def test_struct_sizes_match_header_layout():
     # sizes the C compiler gives the structs of include/rtamd.h on x86-64
     assert C.sizeof(_abi.HitRecord) == 64
