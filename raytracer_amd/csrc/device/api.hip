@@ -375,7 +375,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		// Levels of at least this many hits (RTAMD_PACKETS_FROM; RTAMD_BOUNCE_SHADE=packet: all
 		// that are not "small", =lane: none) are shaded with wave-wide shafts and packets.
 		const char *from = getenv("RTAMD_PACKETS_FROM");
-		sc->bounce.packets_from = from ? (unsigned)strtoul(from, nullptr, 0) : (1u << 21);
+		sc->bounce.packets_from = from ? (unsigned)strtoul(from, nullptr, 0) : (1u << 18);
 		const char *shade = getenv("RTAMD_BOUNCE_SHADE");
 		if (shade && !strcmp(shade, "packet")) sc->bounce.packets_from = 0;
 		if (shade && !strcmp(shade, "lane")) sc->bounce.packets_from = 0xffffffffu;

@@ -188,9 +188,8 @@ def test_noalloc_through_the_per_lane_sorted_kernel(render, monkeypatch):
 def test_frame_large_enough_for_the_default_dispatch(render, monkeypatch, name, least_secondary):
     """The reflective benchmark scenes at their full 640 x 640 with 64 samples per pixel.  8-glossy:
     one chunk, about 20 M rays of depth 1 and as many deeper ones, so the default dispatch
-    sends the dense levels to the packet form of k_bounce_shade (from 2^21 hits), the
-    middle ones to its per-lane form and the thin ones to k_bounce_shade_small, all after
-    the radix sort of the hits.  A window of the frame is compared with the checker, the
+    sends the dense levels to the packet form of k_bounce_shade (from 2^18 hits) and the
+    thin ones to k_bounce_shade_small, all after the radix sort of the hits.  A window of the frame is compared with the checker, the
     whole frame and the ray counts with the unsorted pass, bit for bit."""
     blob = ra.load_sdl(scene_path(name)).with_config(antialiasing=1, aa_samples=8)
     assert (blob.width, blob.height, blob.spp) == (640, 640, 64)
