@@ -76,6 +76,10 @@ struct rtamd_scene {
 	// coherent bounce pass (see kernels.hip): per-entry scratch sized like the queues
 	BounceWork bounce = { nullptr, { nullptr, nullptr }, { nullptr, nullptr }, nullptr, nullptr, nullptr, 0, 0, 0, 1, 0xffffffffu };
 	unsigned bounce_capacity = 0;
+	// Point lights of intensity zero are left out of the device's light list (see
+	// rtamd_scene_create): each is one shadow query per shaded hit, which the kernels do not
+	// count; a shaded hit sends `kept_shadow_rays_per_hit` counted ones.
+	int unlit_point_lights = 0, kept_shadow_rays_per_hit = 0;
 	bool sorted_bounce = false;  // area lights present: bounced hits are shaded in spatial order
 	bool bounce_packets = false; // unsorted pass: queued rays walk as wave-wide packets (mirror-only scenes)
 	int device = -1;             // the device the scene's buffers live on
@@ -273,7 +277,6 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	d.background[0] = h.background[0];
 	d.background[1] = h.background[1];
 	d.background[2] = h.background[2];
-	d.num_lights = h.num_lights;
 	d.num_surfaces = h.num_surfaces;
 	d.has_cubemap = h.has_cubemap;
 
@@ -282,10 +285,52 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 	const rtamd_surface *bs = reinterpret_cast<const rtamd_surface *>(base + h.off_surfaces);
 	const rtamd_mesh *bmesh = reinterpret_cast<const rtamd_mesh *>(base + h.off_meshes);
 
-	std::vector<DevLight> lights(h.num_lights);
+	// A point light of intensity zero (2-transform, 3-aa and 5-primitives have one) gives every
+	// sample the terms Kd * (0 * (N.L * Lc)) and Ks * (0 * (pow(H.N, e) * Lc)) (lighting.c:7-34):
+	// exactly zero when colours are finite and exponents not negative, whether the shadow ray
+	// (shading.c:39-47) is occluded or not.  Such a light is left out of the device's list; its
+	// shadow queries are added to the count when it is read (as many as shaded hits, which is
+	// the kernels' count over the queries per hit of the lights that stay; the last light
+	// always stays).  (Area lights stay: in the serial-stream mode their samples draw from
+	// rand() whatever their intensity.)
+	bool plain_materials = true;
+	for (int i = 0; i < h.num_materials; i++) {
+		plain_materials = plain_materials && bm[i].shininess >= 0;
+		for (int c = 0; c < 3; c++)
+			plain_materials = plain_materials && std::isfinite(bm[i].diffuse[c]) && std::isfinite(bm[i].specular[c]);
+	}
+	const char *keep_unlit = getenv("RTAMD_KEEP_UNLIT_LIGHTS");      // tests: walk them like any other
+	const bool may_drop = plain_materials && !(keep_unlit && atoi(keep_unlit));
+	bool drop[RTAMD_MAX_LIGHTS] = { false };
+	sc->unlit_point_lights = 0;
+	sc->kept_shadow_rays_per_hit = 0;
+	for (int i = 0; i < h.num_lights; i++) {
+		// an area light's keyed sample sequence is named by its place in the list: only point
+		// lights behind the last area light go, so that no place changes
+		bool area_behind = false;
+		for (int k = i + 1; k < h.num_lights; k++)
+			area_behind = area_behind || bl[k].type == RTAMD_LIGHT_AREA;
+		drop[i] = may_drop && !area_behind && bl[i].type == RTAMD_LIGHT_POINT && bl[i].intensity == 0.0f
+			&& std::isfinite(bl[i].colour[0]) && std::isfinite(bl[i].colour[1]) && std::isfinite(bl[i].colour[2]);
+		if (drop[i])
+			sc->unlit_point_lights++;
+		else
+			sc->kept_shadow_rays_per_hit += bl[i].type == RTAMD_LIGHT_AREA ? h.shadow_samples * h.shadow_samples : 1;
+	}
+	for (int i = 0; i < h.num_lights && sc->kept_shadow_rays_per_hit == 0; i++)
+		if (drop[i]) {
+			// the count of shaded hits needs one light that is walked
+			drop[i] = false;
+			sc->unlit_point_lights--;
+			sc->kept_shadow_rays_per_hit = 1;
+		}
+	std::vector<DevLight> lights;
 	bool any_area = false;
 	for (int i = 0; i < h.num_lights; i++) {
-		DevLight &l = lights[i];
+		if (drop[i])
+			continue;
+		lights.emplace_back();
+		DevLight &l = lights.back();
 		std::memset(&l, 0, sizeof l);
 		l.type = bl[i].type;
 		l.intensity = bl[i].intensity;
@@ -297,6 +342,7 @@ static int scene_create_impl(const uint8_t *base, rtamd_scene *sc)
 		l.colour[2] = bl[i].colour[2];
 		any_area |= l.type == RTAMD_LIGHT_AREA;
 	}
+	d.num_lights = (int)lights.size();
 	std::vector<DevMaterial> mats(h.num_materials);
 	for (int i = 0; i < h.num_materials; i++) {
 		DevMaterial &m = mats[i];
@@ -1064,6 +1110,8 @@ static int render_impl(rtamd_scene *sc, const rtamd_render_params &p, const Rend
 		HIP_TRY(hipMemcpy(&c, w.counters, sizeof c, hipMemcpyDeviceToHost));
 		stats->rays_primary = c.rays_primary;
 		stats->rays_shadow = c.rays_shadow;
+		if (sc->unlit_point_lights)
+			stats->rays_shadow += (unsigned long long)sc->unlit_point_lights * (c.rays_shadow / (unsigned)sc->kept_shadow_rays_per_hit);
 		stats->rays_secondary = c.rays_secondary;
 		stats->env_lookups = c.env_lookups;
 		stats->queue_peak = c.queue_peak;

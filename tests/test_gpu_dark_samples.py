@@ -6,7 +6,9 @@ that faces away from the light still receives something, or receives nothing at 
   * a low specular exponent: pow(H.N, e) does not underflow, the sample must be walked
     (an occluder between the surface and the light then decides);
   * exponent 0: pow(0, 0) = 1, every sample of every surface counts;
-  * a light of intensity 0: every sample is dark, on lit and unlit sides alike;
+  * a light of intensity 0: every sample is dark, on lit and unlit sides alike (a point light
+    of that kind is left out of the device's light list altogether, its queries counted:
+    RTAMD_KEEP_UNLIT_LIGHTS=1 keeps it, which is what the comparison build runs with);
   * a negative light colour: the zero diffuse term is -0, which the sum must not see;
   * the scenes' own exponent 400 on bodies that hide half of themselves from the light.
 Against the CPU checker with the same keyed samples: hit records and ray counts exact,
@@ -92,7 +94,7 @@ def cases(tmp_path_factory):
             f.write(SCENE.format(**args))
     assert os.path.exists(WALKALL), "librtamd_walkall.so is not built (make -C raytracer_amd/csrc)"
     out = os.path.join(str(root), "walked.npz")
-    env = dict(os.environ, RTAMD_LIB=WALKALL)
+    env = dict(os.environ, RTAMD_LIB=WALKALL, RTAMD_KEEP_UNLIT_LIGHTS="1")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "render_frames.py")
     subprocess.run([sys.executable, script, out] + list(paths.values()), env=env, check=True, timeout=300)
     walked = np.load(out, allow_pickle=False)
@@ -158,11 +160,11 @@ def test_benchmark_scenes_at_their_own_size(render, tmp_path):
     7-reflections'), at the size and sample counts of their files: product against the
     walk-everything build, whole frame bit for bit, same ray counts."""
     from conftest import scene_path
-    names = ["8-glossy", "7-reflections", "6-soft", "5-primitives"]
+    names = ["8-glossy", "7-reflections", "6-soft", "5-primitives", "3-aa"]
     out = os.path.join(str(tmp_path), "walked.npz")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "render_frames.py")
     subprocess.run([sys.executable, script, out] + [scene_path(n) for n in names],
-                   env=dict(os.environ, RTAMD_LIB=WALKALL), check=True, timeout=600)
+                   env=dict(os.environ, RTAMD_LIB=WALKALL, RTAMD_KEEP_UNLIT_LIGHTS="1"), check=True, timeout=600)
     walked = np.load(out, allow_pickle=False)
     assert str(walked["lib"][0]) == WALKALL
     for name in names:
