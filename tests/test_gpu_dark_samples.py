@@ -50,7 +50,7 @@ SCENE = """<?xml version='1.0' encoding='utf-8'?>
 <Material diffuse_color="0.7 0.7 0.7" specular_color="1 1 1" specular_exponent="{e_floor}" name="floor" />
 <Material diffuse_color="0.9 0.4 0.2" specular_color="1 1 1" specular_exponent="{e_body}" reflect="{reflect}" name="body" />
 </Materials>
-<Scene camera="cam" lights="low,back" background="0.1 0.1 0.2">
+<Scene camera="cam" lights="{lights}" background="0.1 0.1 0.2">
 <Translate vector="0 0 0">
 <Translate vector="-12 0 -12"><Shape geometry="floor" material="floor" /></Translate>
 <Translate vector="-2.2 1.2 0"><Shape geometry="ball" material="body" /></Translate>
@@ -63,7 +63,7 @@ SCENE = """<?xml version='1.0' encoding='utf-8'?>
 """
 
 DEFAULTS = dict(aa=2, point_intensity="0.6", point_colour="1 1 1", area_intensity="0.8", area_colour="1 1 1",
-                e_floor=400, e_body=400, reflect="0.0")
+                e_floor=400, e_body=400, reflect="0.0", lights="low,back")
 
 
 # name -> what differs from DEFAULTS
@@ -71,6 +71,8 @@ CASES = {f"exp-{e}": dict(e_body=e, e_floor=e) for e in (0, 1, 2, 8, 60, 400)}
 CASES.update({
     "area-off": dict(area_intensity="0.0"),
     "all-off": dict(area_intensity="0.0", point_intensity="0"),
+    "point-off-last": dict(point_intensity="0", lights="back,low"),
+    "point-off-only": dict(point_intensity="0", lights="low"),
     "negative": dict(area_colour="-1 0.5 -0.25", point_colour="1 -1 1"),
     "refl-2": dict(aa=2, reflect="0.4", e_body=8),
     "plain-8": dict(aa=8, e_body=8),
@@ -138,6 +140,17 @@ def test_lights_that_give_nothing(render, cases):
     # only the background is left, and surfaces are black
     assert g2[..., :3].max() <= 0.2 + 1e-6
     assert (g2[..., :3].sum(axis=2) == 0).any()
+
+
+def test_unlit_point_light_left_out_of_the_device_list(render, cases):
+    """A zero-intensity point light behind the last area light is not walked at all (its
+    queries are added to the count on readback); before an area light it stays in the list,
+    and as the only light it stays too, so that shaded hits can be counted."""
+    g, st = check(render, cases, "point-off-last")
+    g2, st2 = check(render, cases, "all-off")
+    assert st.rays_shadow == st2.rays_shadow
+    g3, st3 = check(render, cases, "point-off-only")
+    assert st3.rays_shadow > 0 and st3.rays_shadow * 10 == st.rays_shadow
 
 
 def test_negative_light_colour_and_signed_zero(render, cases):
