@@ -144,6 +144,7 @@ DEV void shaft_to_model(CSurface &s, f3 c, f3 r, f3 &cm, f3 &rm)
 #endif
 DEV int shaft_collect(const DevScene &sc, CMesh &mesh, const ShaftTest &st, int *wstack, ShaftEntry *out, int cap)
 {
+	static_assert(4 * RT_MAX_STACK >= 128 && RT_SHAFT_SERIAL_VISITS < 64, "a wave's stack area holds two frontiers of 64 nodes");
 	const u64 exec = __builtin_amdgcn_ballot_w64(true);
 	const u64 below = (1ull << lane_id()) - 1ull;
 	const int rank = __builtin_popcountll(exec & below), lanes = __builtin_popcountll(exec);
