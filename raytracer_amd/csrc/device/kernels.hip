@@ -56,17 +56,17 @@ DEV unsigned slice_count(const QueueSlice &q)
 
 // Primary samples: camera ray, nearest hit, direct lighting with shadow rays,
 // environment lookup; children go to the bounce queue.  raytracer.c:32-54,78-84.
-// Register budget: the primary kernel exists for four waves per SIMD (128 VGPRs, 12
-// spilled dwords per lane) and for five (96 VGPRs, 47 spilled dwords).  The kernel is
+// Register budget: the primary kernel exists for four waves per SIMD (128 VGPRs, 16
+// spilled dwords per lane) and for five (96 VGPRs, 56 spilled dwords).  The kernel is
 // bound by the latency of a wave's own instruction stream as much as by the vector
 // issue rate: three waves measure 16 % slower than four on the 4K showcase frame, and
 // removing 3 % of the vector instructions changes nothing.  Five waves pay where a
-// sample's shadow loops are long (6-soft with 48 shadow rays per hit -5 %,
-// 7-reflections with 50 -6 %, the showcase with 17 -1 %, at the price of 200 GB of
-// spill traffic per 4K frame) and cost where they are short (3-aa +3 %, the five
-// planes of cornell +6 %), six waves are slower everywhere; the launcher takes the
-// five-wave form from RT_LONG_SHADOW_LOOPS shadow rays per hit.  The bounce kernels keep per-lane stacks in LDS (32 KB per workgroup) and run
-// at four.
+// sample's shadow loops are long (the showcase with 17 shadow rays per hit -5 %, 6-soft
+// with 48 -5 %, 7-reflections with 50 -6 %, at the price of 150 GB of spill traffic per
+// 4K frame) and cost where they are short (3-aa +3 %, the five planes of cornell +6 %),
+// six waves are slower everywhere (showcase +9 %); the launcher takes the five-wave form
+// from RT_LONG_SHADOW_LOOPS shadow rays per hit in scenes with area lights.  The bounce
+// kernels keep per-lane stacks in LDS (32 KB per workgroup) and run at four.
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4
 #endif
@@ -74,7 +74,7 @@ DEV unsigned slice_count(const QueueSlice &q)
 #define RT_MIN_WAVES_LONG 5
 #endif
 #ifndef RT_LONG_SHADOW_LOOPS
-#define RT_LONG_SHADOW_LOOPS 32
+#define RT_LONG_SHADOW_LOOPS 16
 #endif
 #ifndef RT_MIN_WAVES_BOUNCE
 #define RT_MIN_WAVES_BOUNCE 4
