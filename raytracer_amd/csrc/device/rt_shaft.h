@@ -262,16 +262,18 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 	const PacketRay pr = make_packet_ray(o, d, tnear, tfar);
 	const double dnear = (double)tnear, dfar = (double)tfar;
 	const float wlo = window_lo(tnear), whi = window_hi(tfar);
-	bool found = false;
+	// the lanes whose ray is occluded, as a lane mask in scalar registers (a per-lane flag
+	// carried round the loops costs two vector instructions wherever it meets a mask)
+	u64 found_m = 0;
+	const u64 lanes = __builtin_amdgcn_ballot_w64(true);
 	RT_STAT(unsigned st_mine = 0; unsigned st_union = 0);
-	RT_STAT(const unsigned st_lanes = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));
+	RT_STAT(const unsigned st_lanes = (unsigned)__builtin_popcountll(lanes));
 	for (int c = 0; c < count; c++) {
 		const ShaftEntry e = list[c];
 		RT_EV(EV_LIST_BOX);
 		float tn;
-		const bool h = packet_box_hit(pr, e.lox, e.loy, e.loz, e.hix, e.hiy, e.hiz, tnear, tfar, tn) && !found;
-		u64 actm = __builtin_amdgcn_ballot_w64(h);
-		RT_STAT(st_mine += h ? 1u : 0u; st_union += actm ? 1u : 0u);
+		u64 actm = __builtin_amdgcn_ballot_w64(packet_box_hit(pr, e.lox, e.loy, e.loz, e.hix, e.hiy, e.hiz, tnear, tfar, tn)) & ~found_m;
+		RT_STAT(st_mine += (actm >> lane_id()) & 1u; st_union += actm ? 1u : 0u);
 		if (actm == 0)
 			continue;
 		const int v = ~__builtin_amdgcn_readfirstlane(e.ref);
@@ -280,18 +282,18 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 			const CONSTAS DevTriEdges &te = edges[first + i];
 			float aa, bb, cc;
 			double t;
-			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
+			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(lanes)) atomicAdd(&g_stat_tris, 1ull));
 			const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
 			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, wlo, whi, aa, bb, cc, t);
-			if (ok && t >= dnear && t <= dfar)
-				found = true;
-			actm &= ~__builtin_amdgcn_ballot_w64(found);
+			found_m |= __builtin_amdgcn_ballot_w64(ok && t >= dnear && t <= dfar);
+			actm &= ~found_m;
 			if (actm == 0)
 				break;
 		}
-		if (__builtin_amdgcn_ballot_w64(!found) == 0)
+		if ((lanes & ~found_m) == 0)
 			break;
 	}
+	const bool found = __builtin_amdgcn_inverse_ballot_w64(found_m);
 #ifdef RT_TRAVERSAL_STATS
 	{
 		unsigned mx = st_mine, sm = st_mine;
