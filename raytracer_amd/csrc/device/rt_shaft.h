@@ -283,8 +283,7 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 			float aa, bb, cc;
 			double t;
 			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(lanes)) atomicAdd(&g_stat_tris, 1ull));
-			const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
-			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act, wlo, whi, aa, bb, cc, t);
+			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), actm, wlo, whi, aa, bb, cc, t);
 			found_m |= __builtin_amdgcn_ballot_w64(ok && t >= dnear && t <= dfar);
 			actm &= ~found_m;
 			if (actm == 0)

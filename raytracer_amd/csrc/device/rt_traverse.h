@@ -99,9 +99,11 @@ typedef unsigned long long u64;
 DEV float window_lo(float tlo) { return tlo - __builtin_fabsf(tlo) * 3.814697265625e-06f - 1e-30f; }
 DEV float window_hi(float thi) { return thi + __builtin_fabsf(thi) * 3.814697265625e-06f + 1e-30f; }
 
-DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool act, float wlo, float whi,
+DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, u64 act, float wlo, float whi,
 		float &aa, float &bb, float &cc, double &t)
 {
+	// (the lanes still in play are carried as a lane mask in scalar registers: a per-lane
+	// flag that meets a ballot costs two vector instructions each time)
 	d3 pvec = vcross(d, edge2);
 	float det = (float)vdot(edge1, pvec);
 	d3 tvec = vsub(o, u);
@@ -109,8 +111,8 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 	const float big = 3.0e38f;
 	const float rdet = __builtin_amdgcn_rcpf(det);
 	const float b_approx = (float)x1 * rdet;
-	bool maybe = act && !((b_approx < -1e-30f && b_approx > -big) || (b_approx > 1.0001f && b_approx < big));
-	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
+	u64 maybe = act & ~__builtin_amdgcn_ballot_w64((b_approx < -1e-30f && b_approx > -big) || (b_approx > 1.0001f && b_approx < big));
+	if (maybe == 0)
 		return false;
 	RT_EV(EV_TRI_STAGE2);
 	d3 qvec = vcross(tvec, edge1);
@@ -120,14 +122,14 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, bool ac
 	const float s_approx = c_approx + b_approx;
 	// relative error of t_approx below 2^-22 whenever it is finite: far inside the window's margin
 	const float t_approx = (float)x3 * rdet;
-	maybe = maybe && !((c_approx < -1e-30f && c_approx > -big) ||
+	maybe &= ~__builtin_amdgcn_ballot_w64((c_approx < -1e-30f && c_approx > -big) ||
 			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big) ||
 			(t_approx < wlo && t_approx > -big) || (t_approx > whi && t_approx < big));
-	if (__builtin_amdgcn_ballot_w64(maybe) == 0)
+	if (maybe == 0)
 		return false;
 	RT_EV(EV_TRI_EXACT);
 	bool ok = false;
-	if (maybe) {
+	if (__builtin_amdgcn_inverse_ballot_w64(maybe)) {
 		bb = (float)(x1 / (double)det);
 		if (!((double)bb < 0.0 || (double)bb > 1.0)) {
 			cc = (float)(x2 / (double)det);
@@ -311,8 +313,7 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 				float aa, bb, cc;
 				double t;
 				RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_stat_tris, 1ull));
-				const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
-				const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), act,
+				const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), actm,
 						wlo, window_hi(limit), aa, bb, cc, t);
 				int orig = te.orig;
 				if (ok && t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
