@@ -284,7 +284,8 @@ DEV bool mesh_candidates_anyhit(const DevScene &sc, CMesh &mesh, d3 o, d3 d, flo
 			double t;
 			RT_STAT(if (lane_id() == (unsigned)__builtin_ctzll(lanes)) atomicAdd(&g_stat_tris, 1ull));
 			const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), actm, wlo, whi, aa, bb, cc, t);
-			found_m |= __builtin_amdgcn_ballot_w64(ok && t >= dnear && t <= dfar);
+			(void)ok;          // t is NaN without a hit
+			found_m |= __builtin_amdgcn_ballot_w64(t >= dnear) & __builtin_amdgcn_ballot_w64(t <= dfar);
 			actm &= ~found_m;
 			if (actm == 0)
 				break;

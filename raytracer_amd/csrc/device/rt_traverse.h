@@ -104,6 +104,8 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, u64 act
 {
 	// (the lanes still in play are carried as a lane mask in scalar registers: a per-lane
 	// flag that meets a ballot costs two vector instructions each time)
+	// a lane that does not hit leaves t = NaN: the callers' window tests then fail by themselves
+	t = __builtin_nan("");
 	d3 pvec = vcross(d, edge2);
 	float det = (float)vdot(edge1, pvec);
 	d3 tvec = vsub(o, u);
@@ -111,7 +113,11 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, u64 act
 	const float big = 3.0e38f;
 	const float rdet = __builtin_amdgcn_rcpf(det);
 	const float b_approx = (float)x1 * rdet;
-	u64 maybe = act & ~__builtin_amdgcn_ballot_w64((b_approx < -1e-30f && b_approx > -big) || (b_approx > 1.0001f && b_approx < big));
+	// (one ballot per comparison, combined as masks: a ballot of a compound condition is
+	// compiled into a vector select and a second comparison)
+#define LANES_WHERE(x) __builtin_amdgcn_ballot_w64(x)
+	u64 maybe = act & ~((LANES_WHERE(b_approx < -1e-30f) & LANES_WHERE(b_approx > -big)) |
+			(LANES_WHERE(b_approx > 1.0001f) & LANES_WHERE(b_approx < big)));
 	if (maybe == 0)
 		return false;
 	RT_EV(EV_TRI_STAGE2);
@@ -122,9 +128,11 @@ DEV bool triangle_intersect_packet(d3 o, d3 d, d3 u, d3 edge1, d3 edge2, u64 act
 	const float s_approx = c_approx + b_approx;
 	// relative error of t_approx below 2^-22 whenever it is finite: far inside the window's margin
 	const float t_approx = (float)x3 * rdet;
-	maybe &= ~__builtin_amdgcn_ballot_w64((c_approx < -1e-30f && c_approx > -big) ||
-			(s_approx > 1.0002f && s_approx < big && __builtin_fabsf(b_approx) < big) ||
-			(t_approx < wlo && t_approx > -big) || (t_approx > whi && t_approx < big));
+	maybe &= ~((LANES_WHERE(c_approx < -1e-30f) & LANES_WHERE(c_approx > -big)) |
+			(LANES_WHERE(s_approx > 1.0002f) & LANES_WHERE(s_approx < big) & LANES_WHERE(__builtin_fabsf(b_approx) < big)) |
+			(LANES_WHERE(t_approx < wlo) & LANES_WHERE(t_approx > -big)) |
+			(LANES_WHERE(t_approx > whi) & LANES_WHERE(t_approx < big)));
+#undef LANES_WHERE
 	if (maybe == 0)
 		return false;
 	RT_EV(EV_TRI_EXACT);
@@ -316,7 +324,8 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 				const bool ok = triangle_intersect_packet(o, d, ld3(te.u), ld3(te.e1), ld3(te.e2), actm,
 						wlo, window_hi(limit), aa, bb, cc, t);
 				int orig = te.orig;
-				if (ok && t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
+				(void)ok;      // t is NaN without a hit
+				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
 					best_t = t;
 					best_orig = orig;
 					best_tri = first + i;
