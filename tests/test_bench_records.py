@@ -20,7 +20,9 @@ def test_counter_record_of_the_bench_workload():
     for key in ("flops_executed_per_launch", "rays_per_launch", "valu_busy", "valu_insts_per_ray", "lane_utilisation",
                 "bytes_per_launch", "l2_hit_rate", "hbm_gbps", "waves_per_simd"):
         assert pmc[key] is not None and pmc[key] > 0, key
-    assert 0.5 < pmc["valu_busy"] <= 1.0 and 0.5 < pmc["l2_hit_rate"] <= 1.0 and 0 < pmc["waves_per_simd"] <= 8
+    # valu_busy divides counters of two passes (two runs of the frame): a kernel that issues
+    # every cycle can come out a fraction of a percent above one; bench.py reports min(1, .)
+    assert 0.5 < pmc["valu_busy"] <= 1.02 and 0.5 < pmc["l2_hit_rate"] <= 1.0 and 0 < pmc["waves_per_simd"] <= 8
     # traffic in bytes per launch: at least the frame itself (3840 x 2160 float4)
     assert bench.measured_traffic(bench.WORKLOAD) > 3840 * 2160 * 16
     assert bench.measured_counters("no-such-scene") is None
