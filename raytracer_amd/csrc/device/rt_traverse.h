@@ -325,25 +325,25 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 						wlo, window_hi(limit), aa, bb, cc, t);
 				int orig = te.orig;
 				(void)ok;      // t is NaN without a hit
-				if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
+				if (ANYHIT) {
+					// any accepted triangle settles a lane (a lane takes part until it is settled,
+					// so its best_t is still +inf): kept as a lane mask, nothing per lane
+					donem |= __builtin_amdgcn_ballot_w64(t >= dnear) & __builtin_amdgcn_ballot_w64(t <= dfar) &
+						__builtin_amdgcn_ballot_w64(t < __builtin_huge_val());
+					actm &= ~donem;
+					if (actm == 0)
+						break;
+				} else if (t >= dnear && t <= dfar && (t < best_t || (t == best_t && orig > best_orig))) {
 					best_t = t;
 					best_orig = orig;
 					best_tri = first + i;
 					ba = aa; bb_ = bb; bc = cc;
 					found = true;
-					if (!ANYHIT) {
-						// next float above or equal to t: boxes further than this cannot win
-						float ft = (float)t;
-						if ((double)ft < t)
-							ft = next_up(ft);
-						limit = ft < tfar ? ft : tfar;
-					}
-				}
-				if (ANYHIT) {
-					donem = __builtin_amdgcn_ballot_w64(found);
-					actm &= ~donem;
-					if (actm == 0)
-						break;
+					// next float above or equal to t: boxes further than this cannot win
+					float ft = (float)t;
+					if ((double)ft < t)
+						ft = next_up(ft);
+					limit = ft < tfar ? ft : tfar;
 				}
 			}
 		}
@@ -353,6 +353,12 @@ DEV bool mesh_traverse_packet(const DevScene &sc, CMesh &mesh, d3 o, d3 d, float
 		for (;;) {
 			if (sp == 0) {
 				TM2_END(TM_IN_POP, t_pop);
+				if (ANYHIT) {
+					// the caller only asks whether: report the hit at the start of its window
+					found = __builtin_amdgcn_inverse_ballot_w64(donem);
+					if (found)
+						best_t = dnear;
+				}
 				return found;
 			}
 			sp--;
